@@ -1,0 +1,101 @@
+"""Build libdfft_mi355x.so and the distFFTOpt driver for gfx950 with hipcc (cross-compiles without a GPU).
+
+Artefacts stay in-tree (distributedfft_amd/lib/) so they travel with the repo snapshot to the GPU box; they are
+git-ignored.  Usage:  python -m distributedfft_amd.build [--force] [--jobs N]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+OBJ = PKG / "lib" / "obj"
+LIBDIR = PKG / "lib"
+INCLUDE = ROOT / "include"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+HIPCC = str(ROCM / "bin" / "hipcc")
+ARCH = "gfx950"
+NUM_INST_GROUPS = 7  # keep in sync with csrc/dfft_plans.h
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + str(INCLUDE), "-I" + str(CSRC),
+          "-Wno-unused-result"]
+
+LIB_NAME = "libdfft_mi355x.so"
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return r
+
+
+def _headers():
+    return sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h")) + list(INCLUDE.glob("*/*.h")))
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> Path:
+    OBJ.mkdir(parents=True, exist_ok=True)
+    hdrs = _headers()
+    units = []  # (source, object, extra flags)
+    for g in range(NUM_INST_GROUPS):
+        units.append((CSRC / "dfft_fft_inst.hip", OBJ / f"dfft_fft_inst_{g}.o", [f"-DDFFT_INST_GROUP={g}"]))
+    units.append((CSRC / "dfft_kernels.hip", OBJ / "dfft_kernels.o", []))
+    for name in ("dfft_plan", "dfft_exchange", "dfft_bootstrap"):
+        units.append((CSRC / f"{name}.cpp", OBJ / f"{name}.o", ["-x", "hip"]))
+
+    def compile_one(u):
+        src, obj, extra = u
+        if not force and not _newer(obj, [src] + hdrs):
+            return False
+        cmd = [HIPCC] + COMMON + extra + ["-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        _run(cmd)
+        return True
+
+    jobs = jobs or min(8, os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        rebuilt = list(ex.map(compile_one, units))
+
+    lib = LIBDIR / LIB_NAME
+    objs = [str(u[1]) for u in units]
+    if force or any(rebuilt) or _newer(lib, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(lib)] + objs +
+             ["-L" + str(ROCM / "lib"), "-lrccl", "-Wl,-rpath," + str(ROCM / "lib")])
+
+    # driver: our clone, built against the MPI shim (no MPI installation needed)
+    drv = LIBDIR / "distFFTOpt"
+    drv_src = CSRC / "distFFTOpt.cpp"
+    if force or _newer(drv, [drv_src, lib] + hdrs):
+        _run([HIPCC] + COMMON + ["-x", "hip", "-I" + str(INCLUDE / "dfft_mpi_shim"), str(drv_src), "-x", "none",
+                                 "-o", str(drv), "-L" + str(LIBDIR), "-ldfft_mi355x", "-lpthread",
+                                 "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
+    return lib
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("-v", "--verbose", action="store_true")
+    a = ap.parse_args()
+    lib = build(a.force, a.jobs, a.verbose)
+    print(lib)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

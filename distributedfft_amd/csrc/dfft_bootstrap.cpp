@@ -1,0 +1,210 @@
+// dfft_bootstrap.cpp -- minimal TCP rendezvous (star over rank 0) for multi-process launches without MPI.
+//
+// The reference driver uses MPI for four control-plane things only (fftSpeed3d_c2c.cpp:18-26, 120-124, and the dead
+// ncclUniqueId broadcast in fft_mpi_3d_api.cpp:29-37): rank/size, a broadcast, a barrier and a MAX reduction.  The data
+// plane (t2) is RCCL here, so a ~200-line socket layer replaces the MPI dependency.  Not a general MPI: blocking, root 0
+// hub, intended for <= a few dozen ranks on one node.
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "dfft_internal.h"
+
+namespace {
+
+struct Boot {
+    bool             inited = false;
+    int              rank = 0, size = 1;
+    int              hub = -1;        // non-root: socket to rank 0
+    std::vector<int> peers;           // root: socket per rank (index = rank; [0] unused)
+} g;
+
+const char* env_first(std::initializer_list<const char*> names) {
+    for (const char* n : names) {
+        const char* v = getenv(n);
+        if (v && *v) return v;
+    }
+    return nullptr;
+}
+
+bool send_all(int fd, const void* buf, size_t n) {
+    const char* p = (const char*)buf;
+    while (n) {
+        ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+bool recv_all(int fd, void* buf, size_t n) {
+    char* p = (char*)buf;
+    while (n) {
+        ssize_t k = ::recv(fd, p, n, 0);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        if (k == 0) return false;
+        p += k;
+        n -= (size_t)k;
+    }
+    return true;
+}
+
+}  // namespace
+
+using namespace dfft;
+
+extern "C" {
+
+int dfft_boot_init(void) {
+    if (g.inited) return DFFT_OK;
+    const char* r = env_first({"DFFT_RANK", "RANK", "PMI_RANK", "OMPI_COMM_WORLD_RANK"});
+    const char* s = env_first({"DFFT_WORLD_SIZE", "WORLD_SIZE", "PMI_SIZE", "OMPI_COMM_WORLD_SIZE"});
+    g.rank = r ? atoi(r) : 0;
+    g.size = s ? atoi(s) : 1;
+    if (g.size < 1 || g.rank < 0 || g.rank >= g.size) return fail(DFFT_ECOMM, "dfft_boot_init: inconsistent rank/size");
+    if (g.size == 1) {
+        g.inited = true;
+        return DFFT_OK;
+    }
+    const char* addr = env_first({"DFFT_MASTER_ADDR", "MASTER_ADDR"});
+    const char* port = env_first({"DFFT_MASTER_PORT", "MASTER_PORT"});
+    if (!addr) addr = "127.0.0.1";
+    int portno = port ? atoi(port) : 29533;
+    if (!getenv("DFFT_MASTER_PORT") && getenv("MASTER_PORT")) portno += 1;  // stay off torchrun's own store port
+
+    if (g.rank == 0) {
+        int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (ls < 0) return fail(DFFT_ECOMM, "dfft_boot_init: socket()");
+        int one = 1;
+        setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+        sockaddr_in sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sin_family = AF_INET;
+        sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        sa.sin_port = htons((uint16_t)portno);
+        if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, g.size) != 0) {
+            ::close(ls);
+            return fail(DFFT_ECOMM, std::string("dfft_boot_init: bind/listen on port ") + std::to_string(portno) + ": " +
+                                        strerror(errno));
+        }
+        g.peers.assign(g.size, -1);
+        for (int i = 1; i < g.size; ++i) {
+            int fd = ::accept(ls, nullptr, nullptr);
+            if (fd < 0) {
+                ::close(ls);
+                return fail(DFFT_ECOMM, "dfft_boot_init: accept()");
+            }
+            setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+            int32_t pr = -1;
+            if (!recv_all(fd, &pr, sizeof(pr)) || pr < 1 || pr >= g.size || g.peers[pr] != -1) {
+                ::close(fd);
+                ::close(ls);
+                return fail(DFFT_ECOMM, "dfft_boot_init: bad hello from a peer");
+            }
+            g.peers[pr] = fd;
+        }
+        ::close(ls);
+    } else {
+        addrinfo hints, *res = nullptr;
+        std::memset(&hints, 0, sizeof(hints));
+        hints.ai_family = AF_INET;
+        hints.ai_socktype = SOCK_STREAM;
+        const std::string ps = std::to_string(portno);
+        if (getaddrinfo(addr, ps.c_str(), &hints, &res) != 0 || !res)
+            return fail(DFFT_ECOMM, std::string("dfft_boot_init: cannot resolve ") + addr);
+        int fd = -1;
+        for (int attempt = 0; attempt < 600; ++attempt) {  // rank 0 may start later: retry for ~60 s
+            fd = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+            if (fd >= 0) ::close(fd);
+            fd = -1;
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        }
+        freeaddrinfo(res);
+        if (fd < 0) return fail(DFFT_ECOMM, "dfft_boot_init: cannot reach rank 0");
+        int one = 1;
+        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        int32_t me = g.rank;
+        if (!send_all(fd, &me, sizeof(me))) return fail(DFFT_ECOMM, "dfft_boot_init: hello failed");
+        g.hub = fd;
+    }
+    g.inited = true;
+    return DFFT_OK;
+}
+
+int dfft_boot_rank(void) { return g.rank; }
+int dfft_boot_size(void) { return g.size; }
+
+int dfft_boot_bcast(void* buf, size_t bytes, int root) {
+    if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
+    if (g.size == 1 || bytes == 0) return DFFT_OK;
+    if (root != 0) {  // route through the hub
+        if (g.rank == root) {
+            if (!send_all(g.hub, buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send");
+        } else if (g.rank == 0) {
+            if (!recv_all(g.peers[root], buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: recv");
+        }
+    }
+    if (g.rank == 0) {
+        for (int i = 1; i < g.size; ++i)
+            if (i != root || root == 0)
+                if (!send_all(g.peers[i], buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send");
+    } else if (g.rank != root) {
+        if (!recv_all(g.hub, buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: recv");
+    }
+    return DFFT_OK;
+}
+
+int dfft_boot_allreduce_max(double* v, int n) {
+    if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
+    if (g.size == 1 || n <= 0) return DFFT_OK;
+    const size_t bytes = sizeof(double) * (size_t)n;
+    if (g.rank == 0) {
+        std::vector<double> tmp(n);
+        for (int i = 1; i < g.size; ++i) {
+            if (!recv_all(g.peers[i], tmp.data(), bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: recv");
+            for (int k = 0; k < n; ++k)
+                if (tmp[k] > v[k]) v[k] = tmp[k];
+        }
+        for (int i = 1; i < g.size; ++i)
+            if (!send_all(g.peers[i], v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: send");
+    } else {
+        if (!send_all(g.hub, v, bytes) || !recv_all(g.hub, v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max");
+    }
+    return DFFT_OK;
+}
+
+int dfft_boot_barrier(void) {
+    double z = 0;
+    return dfft_boot_allreduce_max(&z, 1);
+}
+
+int dfft_boot_finalize(void) {
+    if (!g.inited) return DFFT_OK;
+    if (g.size > 1) dfft_boot_barrier();
+    if (g.hub >= 0) ::close(g.hub);
+    for (int fd : g.peers)
+        if (fd >= 0) ::close(fd);
+    g.peers.clear();
+    g.hub = -1;
+    g.inited = false;
+    return DFFT_OK;
+}
+
+}  // extern "C"

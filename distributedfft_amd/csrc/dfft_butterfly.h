@@ -1,0 +1,123 @@
+// dfft_butterfly.h -- in-register radix-2/3/4/5/8 DFT butterflies for the Stockham stages.
+//
+// Replaces (behaviour only) the butterfly bodies the reference's run-time code generator emits:
+//   /root/reference/templateFFT/src/templateFFT.cpp:315-1075 (inlineRadixKernelFFT, cases 2/3/4/5/8).
+// Everything here is static C++ for gfx950; there is no string code generator and no hiprtc.
+//
+// Conventions
+//   V    = double2 (fp64 path) or float2 (fp32 path): one complex number, .x = re, .y = im.
+//   DIR  = +1 forward  (kernel e^{-i theta}, reference FORWARD,  fft_mpi_common.h:18)
+//        = -1 backward (kernel e^{+i theta}, reference BACKWARD, fft_mpi_common.h:19), unnormalised.
+//   butterfly<R, DIR>(u): u[0..R-1] in, natural-order DFT of length R out (u[k] = sum_n u[n] w^{nk}).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dfft {
+
+template <class V> struct real_of;
+template <> struct real_of<double2> { using type = double; };
+template <> struct real_of<float2>  { using type = float; };
+
+template <class V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
+template <class V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
+template <class V> __device__ __forceinline__ V cmul(V a, V b) {
+    // (a.x + i a.y)(b.x + i b.y); the compiler contracts these into fma chains.
+    return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by e^{-i DIR pi/2}: forward -> times (-i), backward -> times (+i)
+template <int DIR, class V> __device__ __forceinline__ V mul_mi(V a) {
+    if (DIR > 0) return V{a.y, -a.x};
+    return V{-a.y, a.x};
+}
+template <class V, class R> __device__ __forceinline__ V cscale(V a, R s) { return V{a.x * s, a.y * s}; }
+
+template <int R, int DIR, class V> struct Butterfly;
+
+template <int DIR, class V> struct Butterfly<1, DIR, V> {
+    static __device__ __forceinline__ void run(V*) {}
+};
+
+template <int DIR, class V> struct Butterfly<2, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        V a = u[0], b = u[1];
+        u[0] = cadd(a, b);
+        u[1] = csub(a, b);
+    }
+};
+
+template <int DIR, class V> struct Butterfly<3, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        using Rt = typename real_of<V>::type;
+        const Rt half = Rt(0.5), s32 = Rt(0.86602540378443864676372317075294);  // sin(pi/3)
+        V t = cadd(u[1], u[2]);
+        V d = cscale(csub(u[1], u[2]), s32);
+        V m = V{u[0].x - half * t.x, u[0].y - half * t.y};
+        V r = mul_mi<DIR>(d);
+        u[0] = cadd(u[0], t);
+        u[1] = cadd(m, r);
+        u[2] = csub(m, r);
+    }
+};
+
+template <int DIR, class V> struct Butterfly<4, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        V t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]);
+        V t2 = cadd(u[1], u[3]), t3 = mul_mi<DIR>(csub(u[1], u[3]));
+        u[0] = cadd(t0, t2);
+        u[2] = csub(t0, t2);
+        u[1] = cadd(t1, t3);
+        u[3] = csub(t1, t3);
+    }
+};
+
+template <int DIR, class V> struct Butterfly<5, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        using Rt = typename real_of<V>::type;
+        const Rt c1 = Rt(0.30901699437494742410229341718282);   // cos(2pi/5)
+        const Rt c2 = Rt(-0.80901699437494742410229341718282);  // cos(4pi/5)
+        const Rt s1 = Rt(0.95105651629515357211643933337938);   // sin(2pi/5)
+        const Rt s2 = Rt(0.58778525229247312916870595463907);   // sin(4pi/5)
+        V t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]);
+        V t3 = csub(u[1], u[4]), t4 = csub(u[2], u[3]);
+        V m1 = V{u[0].x + c1 * t1.x + c2 * t2.x, u[0].y + c1 * t1.y + c2 * t2.y};
+        V m2 = V{u[0].x + c2 * t1.x + c1 * t2.x, u[0].y + c2 * t1.y + c1 * t2.y};
+        V q1 = mul_mi<DIR>(V{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});
+        V q2 = mul_mi<DIR>(V{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
+        u[0] = V{u[0].x + t1.x + t2.x, u[0].y + t1.y + t2.y};
+        u[1] = cadd(m1, q1);
+        u[4] = csub(m1, q1);
+        u[2] = cadd(m2, q2);
+        u[3] = csub(m2, q2);
+    }
+};
+
+template <int DIR, class V> struct Butterfly<8, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        using Rt = typename real_of<V>::type;
+        const Rt h = Rt(0.70710678118654752440084436210485);  // 1/sqrt(2)
+        V e[4] = {u[0], u[2], u[4], u[6]};
+        V o[4] = {u[1], u[3], u[5], u[7]};
+        Butterfly<4, DIR, V>::run(e);
+        Butterfly<4, DIR, V>::run(o);
+        // o[k] *= W8^k, W8 = e^{-i DIR pi/4}
+        V o1, o3;
+        if (DIR > 0) {
+            o1 = V{(o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h};
+            o3 = V{(o[3].y - o[3].x) * h, -(o[3].x + o[3].y) * h};
+        } else {
+            o1 = V{(o[1].x - o[1].y) * h, (o[1].x + o[1].y) * h};
+            o3 = V{-(o[3].x + o[3].y) * h, (o[3].x - o[3].y) * h};
+        }
+        V o2 = mul_mi<DIR>(o[2]);
+        u[0] = cadd(e[0], o[0]);
+        u[4] = csub(e[0], o[0]);
+        u[1] = cadd(e[1], o1);
+        u[5] = csub(e[1], o1);
+        u[2] = cadd(e[2], o2);
+        u[6] = csub(e[2], o2);
+        u[3] = cadd(e[3], o3);
+        u[7] = csub(e[3], o3);
+    }
+};
+
+}  // namespace dfft

@@ -1,0 +1,307 @@
+// dfft_fft_impl.h -- the Stockham FFT kernel template for gfx950 (wave64, LDS exchange, register twiddles).
+//
+// One template serves every FFT on the slab pipeline's hot path:
+//   t0 Z pass  : contiguous rows            (reference K0a, templateFFT.cpp:6085-6086, fft_mpi_3d_api.cpp:496-511)
+//   t0 Y pass  : stride-N2 columns + fused t1 pack  (reference K0b + K1, kernel_func.cpp:73-86)
+//   t3 X pass  : stride-(yl*N2) columns + fused transposing store (reference K3a + K3b, fft_mpi_3d_api.cpp:539-551)
+// and their inverses.  It is NOT a translation of the generated reference kernels:
+//   * each thread loads its E points straight from HBM in the pattern the first radix stage consumes
+//     (idx = j + T*k), and the last stage leaves results in that same pattern, so a whole FFT needs only
+//     (stages-1) LDS exchanges (reference: stages+1 LDS round trips, 2*stages barriers);
+//   * a 512-point FFT is exactly one wave64 (64 lanes x 8 points): the row kernel needs no s_barrier at all;
+//   * twiddles e^{-2 pi i r m / (Ns R)} are fetched once per persistent thread into VGPRs and reused for every
+//     tile the block processes (reference: global LUT read per stage per FFT);
+//   * the column kernel keeps CB adjacent columns as the fastest LDS dimension, so every ds_write_b128 /
+//     ds_read_b128 lane group is contiguous (bank-conflict free without padding) and every HBM access is a
+//     full 128-byte line; pack (t1) and the X transpose are folded into the store address map.
+//
+// Stockham stage (Ns = product of earlier radices, butterfly id jq = j + q*T, q < E/R):
+//   u[r]  = v[q + r*E/R] * w^{r*(jq mod Ns)},  w = e^{-2 pi i DIR/(Ns*R)}
+//   u     = DFT_R(u)
+//   dst   = (jq / Ns) * Ns * R + (jq mod Ns) + r*Ns        (scatter through LDS, skipped for the last stage)
+#pragma once
+#include "dfft_butterfly.h"
+#include "dfft_kernels.h"
+
+namespace dfft {
+
+template <int N_, int E_, int... Rs> struct Plan {
+    static constexpr int N = N_, E = E_, T = N_ / E_, S = sizeof...(Rs);
+    static constexpr int R[sizeof...(Rs)] = {Rs...};
+    static_assert((Rs * ... * 1) == N_, "radix product must equal N");
+    static_assert(((E_ % Rs == 0) && ...), "every radix must divide E");
+    static_assert(N_ % E_ == 0, "E must divide N");
+};
+
+template <class P, int S> struct StageInfo {
+    using Prev = StageInfo<P, S - 1>;
+    static constexpr int R = P::R[S];
+    static constexpr int NS = Prev::NS * Prev::R;
+    static constexpr int B = P::E / R;
+    static constexpr int TWOFF = Prev::TWOFF + Prev::TWCNT;
+    static constexpr int TWCNT = B * (R - 1);
+};
+template <class P> struct StageInfo<P, 0> {
+    static constexpr int R = P::R[0];
+    static constexpr int NS = 1;
+    static constexpr int B = P::E / R;
+    static constexpr int TWOFF = 0;
+    static constexpr int TWCNT = 0;
+};
+template <class P> struct TwTotal {
+    using L = StageInfo<P, P::S - 1>;
+    static constexpr int value = L::TWOFF + L::TWCNT;
+};
+
+template <int CB, bool PAD> __device__ __forceinline__ int lds_index(int idx, int c) {
+    // CB == 1 (row kernel): one pad element every 8 keeps the stride-R scatter of the first stage on
+    // distinct banks for ds_write_b128 (stride 9*16 B) and ds_write_b64 (stride 9*8 B).
+    const int p = PAD ? idx + (idx >> 3) : idx;
+    return p * CB + c;
+}
+
+template <bool WAVE_LOCAL> __device__ __forceinline__ void group_sync() {
+    if (WAVE_LOCAL) {
+        // The whole FFT lives in one wavefront: DS operations of a wave are processed in issue order, so only
+        // the compiler has to be kept from reordering across the exchange.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <class V, class P, int S, int DIR> __device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, int j) {
+    if constexpr (S < P::S) {
+        using SI = StageInfo<P, S>;
+        if constexpr (S > 0) {
+#pragma unroll
+            for (int q = 0; q < SI::B; ++q) {
+                const int m = (j + q * P::T) % SI::NS;
+#pragma unroll
+                for (int r = 1; r < SI::R; ++r) {
+                    V w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
+                    if (DIR < 0) w.y = -w.y;
+                    twr[SI::TWOFF + q * (SI::R - 1) + (r - 1)] = w;
+                }
+            }
+        }
+        load_twiddles<V, P, S + 1, DIR>(twr, tw, j);
+    }
+}
+
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, bool TWLDS>
+__device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, int c) {
+    using SI = StageInfo<P, S>;
+    constexpr int R = SI::R, B = SI::B, NS = SI::NS, T = P::T, E = P::E;
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+        V u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = v[q + r * B];
+        if constexpr (S > 0) {
+            if constexpr (TWLDS) {
+                // twr = direction-adjusted N-entry table staged in LDS (plans whose twiddle set would not fit VGPRs)
+                const int m = ((j + q * T) % NS) * (P::N / (NS * R));
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[r * m]);
+            } else {
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[SI::TWOFF + q * (R - 1) + (r - 1)]);
+            }
+        }
+        Butterfly<R, DIR, V>::run(u);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[q + r * B] = u[r];
+    }
+    if constexpr (S + 1 < P::S) {
+        if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            const int jq = j + q * T;
+            const int base = (jq / NS) * (NS * R) + (jq % NS);
+#pragma unroll
+            for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
+        }
+        group_sync<WAVE_LOCAL>();
+#pragma unroll
+        for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWLDS>(v, twr, lds, j, c);
+    }
+}
+
+template <class V, class P, int CB, int G> struct KernelGeom {
+    static constexpr int GT = CB * P::T;  // threads cooperating on one tile
+    static constexpr int THREADS = GT * G;
+    static constexpr bool WAVE_LOCAL = (GT <= 64) && (64 % GT == 0);
+    static constexpr bool PAD = (CB * (int)sizeof(V) < 128) && (P::N >= 16);
+    static constexpr int LDS_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
+    // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex), otherwise in an LDS copy of the table.
+    static constexpr bool TWLDS = TwTotal<P>::value > 16;
+    static constexpr int TW_ELEMS = TWLDS ? P::N : 0;
+    static constexpr size_t LDS_BYTES = ((size_t)LDS_ELEMS * G + TW_ELEMS) * sizeof(V);
+};
+
+// GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
+template <class V, class P, int CB, int G, int DIR, bool GENERAL>
+__global__ void __launch_bounds__((KernelGeom<V, P, CB, G>::THREADS))
+fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, AxisMap omap,
+                 TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, int ncols) {
+    using KG = KernelGeom<V, P, CB, G>;
+    constexpr int E = P::E, T = P::T, GT = KG::GT;
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    V* ldstw = reinterpret_cast<V*>(dfft_smem);
+    V* lds = ldstw + KG::TW_ELEMS + (threadIdx.x / GT) * KG::LDS_ELEMS;
+
+    const int g = threadIdx.x / GT;
+    const int tid = threadIdx.x - g * GT;
+    const int c = tid % CB;
+    const int j = tid / CB;
+
+    constexpr int TWN = KG::TWLDS ? 0 : TwTotal<P>::value;
+    V twreg[TWN > 0 ? TWN : 1];
+    const V* twr = twreg;
+    if constexpr (KG::TWLDS) {
+        for (int i = threadIdx.x; i < P::N; i += KG::THREADS) {
+            V w = tw[i];
+            if (DIR < 0) w.y = -w.y;
+            ldstw[i] = w;
+        }
+        __syncthreads();
+        twr = ldstw;
+    } else {
+        load_twiddles<V, P, 0, DIR>(twreg, tw, j);
+    }
+
+    // Per-thread element offsets of its E points relative to the tile base (constant over tiles).
+    unsigned irel[E], orel[E];
+    unsigned ilast = 0, olast = 0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int idx = j + T * k;
+        const int ib = idx / imap.blk, ob = idx / omap.blk;
+        irel[k] = (unsigned)(ib * imap.blk_stride + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
+        orel[k] = (unsigned)(ob * omap.blk_stride + (idx - ob * omap.blk) * omap.stride + c * omap.cstride);
+        if (GENERAL) {
+            if (ib == imap.nblk - 1) ilast |= 1u << k;
+            if (ob == omap.nblk - 1) olast |= 1u << k;
+        }
+    }
+
+    const unsigned tstep = gridDim.x * G;
+    for (unsigned t0 = blockIdx.x * G; t0 < ntiles; t0 += tstep) {
+        const unsigned tile = t0 + g;
+        bool valid = tile < ntiles;
+        const unsigned a = tile / tiles_per_a;
+        const unsigned b = tile - a * tiles_per_a;
+        if (GENERAL) valid = valid && ((int)(b * CB) + c < ncols);
+        const V* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
+        V* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
+
+        V v[E];
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                long long off = irel[k];
+                if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
+                v[k] = ip[off];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = V{0, 0};
+        }
+
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWLDS>(v, twr, lds, j, c);
+
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                long long off = orel[k];
+                if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
+                op[off] = v[k];
+            }
+        }
+    }
+}
+
+struct DeviceInfo {
+    int cus;
+};
+inline const DeviceInfo& device_info() {
+    static thread_local int cached_dev = -1;
+    static thread_local DeviceInfo di;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != cached_dev) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) di.cus = p.multiProcessorCount;
+        else di.cus = 256;
+        cached_dev = dev;
+    }
+    return di;
+}
+
+template <class V, class P, int CB, int G, int DIR, bool GENERAL>
+hipError_t launch_variant(const FftLaunch& L, hipStream_t stream) {
+    using KG = KernelGeom<V, P, CB, G>;
+    auto kern = fft_tiles_kernel<V, P, CB, G, DIR, GENERAL>;
+    // blocks/CU is a property of the kernel; computed once per process (same for all gfx950 devices).
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        if (KG::LDS_BYTES > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)KG::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        int occ = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, KG::THREADS, KG::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = occ > 0 ? occ : 1;
+    }
+    const long long nblocks_needed = (L.ntiles + G - 1) / G;
+    long long grid = (long long)device_info().cus * blocks_per_cu;
+    if (grid > nblocks_needed) grid = nblocks_needed;
+    if (grid < 1) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const V*)L.in, (V*)L.out,
+                       (const V*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles, (unsigned)L.tiles_per_a,
+                       L.ncols);
+    return hipGetLastError();
+}
+
+template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };
+
+// Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex) unless the
+// tile would exceed 128 KiB of LDS or 1024 threads, then halve (2048-point fp64 -> 4 columns).
+template <class V, class P> constexpr int cols_per_tile() {
+    int cb = 128 / (int)sizeof(V);
+    while (cb > 1 && ((long long)P::N * cb * (long long)sizeof(V) > 128 * 1024 || cb * P::T > 1024)) cb /= 2;
+    return cb;
+}
+
+template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream_t stream) {
+    constexpr int CBC = cols_per_tile<V, P>();
+    constexpr int GR = ConstMax1<256 / P::T>::value;          // row kernel: ~256 threads per block
+    constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
+    const bool general = L.cols && ((L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0);
+    if (!L.cols) {
+        if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
+        return launch_variant<V, P, 1, GR, -1, false>(L, stream);
+    }
+    if constexpr (CBC * P::T <= 1024) {
+        if (L.dir > 0) {
+            if (general) return launch_variant<V, P, CBC, GC, +1, true>(L, stream);
+            return launch_variant<V, P, CBC, GC, +1, false>(L, stream);
+        }
+        if (general) return launch_variant<V, P, CBC, GC, -1, true>(L, stream);
+        return launch_variant<V, P, CBC, GC, -1, false>(L, stream);
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
+// One entry point per FFT length, explicitly instantiated in dfft_fft_inst.hip (split over translation units so the
+// gfx950 code objects build in parallel).
+template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream);
+
+}  // namespace dfft

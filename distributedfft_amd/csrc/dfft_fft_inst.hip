@@ -1,0 +1,72 @@
+// dfft_fft_inst.hip -- explicit instantiations of the FFT kernel template, one group of lengths per
+// translation unit (compile with -DDFFT_INST_GROUP=<g>, g in [0, DFFT_NUM_INST_GROUPS)).
+#include "dfft_fft_impl.h"
+#include "dfft_plans.h"
+
+#ifndef DFFT_INST_GROUP
+#error "compile with -DDFFT_INST_GROUP=<g>"
+#endif
+
+namespace dfft {
+
+template <int N> struct PlanFor;
+#define DFFT_DECL_PLAN(N, GRP, E, ...) \
+    template <> struct PlanFor<N> { using type = Plan<N, E, __VA_ARGS__>; static constexpr int group = GRP; };
+DFFT_PLAN_TABLE(DFFT_DECL_PLAN)
+#undef DFFT_DECL_PLAN
+
+template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
+    using P = typename PlanFor<N>::type;
+    if (L.dtype == F64) return launch_plan<double2, P>(L, stream);
+    if (L.dtype == F32) return launch_plan<float2, P>(L, stream);
+    return hipErrorInvalidValue;
+}
+
+template <int N> int cols_n(int dtype) {
+    using P = typename PlanFor<N>::type;
+    return dtype == F64 ? cols_per_tile<double2, P>() : cols_per_tile<float2, P>();
+}
+#define DFFT_INST_PLAN(N, GRP, E, ...) DFFT_INST_IF_##GRP(N)
+#define DFFT_DO_INST(N)                                                       \
+    template hipError_t launch_n<N>(const FftLaunch&, hipStream_t);          \
+    template int cols_n<N>(int);
+
+#if DFFT_INST_GROUP == 0
+#define DFFT_INST_IF_0(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_0(N)
+#endif
+#if DFFT_INST_GROUP == 1
+#define DFFT_INST_IF_1(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_1(N)
+#endif
+#if DFFT_INST_GROUP == 2
+#define DFFT_INST_IF_2(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_2(N)
+#endif
+#if DFFT_INST_GROUP == 3
+#define DFFT_INST_IF_3(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_3(N)
+#endif
+#if DFFT_INST_GROUP == 4
+#define DFFT_INST_IF_4(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_4(N)
+#endif
+#if DFFT_INST_GROUP == 5
+#define DFFT_INST_IF_5(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_5(N)
+#endif
+#if DFFT_INST_GROUP == 6
+#define DFFT_INST_IF_6(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_6(N)
+#endif
+
+DFFT_PLAN_TABLE(DFFT_INST_PLAN)
+
+}  // namespace dfft

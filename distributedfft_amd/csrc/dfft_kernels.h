@@ -1,0 +1,64 @@
+// dfft_kernels.h -- host-side launch descriptors for the gfx950 FFT / reorder kernels.
+// Internal header (not part of the C-ABI; that is include/dfft.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dfft {
+
+enum DType { F64 = 0, F32 = 1 };
+
+// Maps (FFT index idx in [0,N), column c in [0,CB)) to an element offset relative to the tile base:
+//   off = (idx / blk) * blk_stride + (idx % blk) * stride + c * cstride
+//         + (idx / blk == nblk-1 ? a * last_delta : 0)          (uneven last slab)
+// blk == N (one block) for plain strided access.
+struct AxisMap {
+    int       blk;
+    int       nblk;
+    long long blk_stride;
+    long long stride;
+    long long cstride;
+    long long last_delta;
+};
+
+// tile -> (a = tile / tiles_per_a, b = tile % tiles_per_a); base = a * a_stride + b * CB * b_stride
+struct TileMap {
+    long long a_stride;
+    long long b_stride;
+};
+
+struct FftLaunch {
+    int         dtype;  // DType
+    int         n;      // FFT length
+    int         dir;    // +1 forward, -1 backward (unnormalised both ways)
+    int         cols;   // 0: "row" kernel (one FFT per tile, contiguous, wave-local);
+                        // 1: "column" kernel (CB adjacent columns per tile, block-wide)
+    const void* in;
+    void*       out;
+    const void* tw;     // N-entry table of e^{-2 pi i k / N} in the kernel's dtype
+    AxisMap     imap, omap;
+    TileMap     itile, otile;
+    long long   ntiles;
+    int         tiles_per_a;
+    int         ncols;  // number of valid columns along the tiled dimension (guard for ragged last tile)
+};
+
+// Column-tile width (elements) the column kernel uses for length n: 128 B per row segment unless LDS-bound.
+int  fft_cols_per_tile(int dtype, int n);
+bool fft_length_supported(int n);
+// Returns hipErrorInvalidValue for unsupported (n, dtype); otherwise the launch status.
+hipError_t launch_fft(const FftLaunch& L, hipStream_t stream);
+
+// Reference-structure (un-fused) reorder kernels, kept so t1 / the t3 transpose stay separately
+// measurable.
+//   pack  : [xl][N1][N2] -> [d][xl][yl_d][N2]   (kernel_func.cpp:73-86), dir=+1; inverse for dir=-1
+//   trans : 2D transpose of a rows x cols matrix of complex elements through a padded LDS tile
+//           (replaces dev_transpose_201_ept1 / _120_ept1, kernels_201.cpp:28-70, kernels_120.cpp:28-70)
+hipError_t launch_pack(int dtype, int dir, const void* in, void* out, int xl, int n1, int n2, int yl,
+                       int ylast, int P, hipStream_t stream);
+hipError_t launch_transpose(int dtype, const void* in, void* out, long long rows, long long cols,
+                            hipStream_t stream);
+// out[i] = in[i] * s (used only by the optional normalised inverse of the host mirror)
+hipError_t launch_scale(int dtype, void* data, long long count, double s, hipStream_t stream);
+
+}  // namespace dfft

@@ -1,0 +1,684 @@
+// dfft_plan.cpp -- slab bookkeeping, plan object and the t0..t3 execute sequence behind the C-ABI (include/dfft.h).
+//
+// Reference being replaced (behaviour, not code): /root/reference/3dmpifft_opt/include/fft_mpi_3d_api.cpp
+//   fft_mpi_init :3-39, fft_mpi_plan_dft_c2c_3d :41-141, fft_mpi_destroy_plan :143-179,
+//   fft_mpi_execute_dft_3d_c2c :181-214, getProperDeviceNum :232-272, getDataCountForNode :274-287,
+//   getMaxDataCount :289-316, fftZY :466-522, fftX :524-573, localTransposeUneven :575-608, slabAlltoall :610-672.
+//
+// MI355X-first differences (DESIGN.md has the full list):
+//   * t0 is two launches over the WHOLE slab (Z rows, Y columns), not 2*xl per-plane launches;
+//   * fused mode: the Y pass stores straight into the packed [dest][xl][yl][N2] send layout (t1 disappears) and the
+//     X pass loads [x][yl][N2] column tiles and stores [yl][N2][kx] (the 16x16 tile transpose disappears):
+//     6*S bytes per element of HBM traffic for the local pipeline instead of the reference's 10*S;
+//   * P == 1 short-circuits the exchange (the reference does a full-size self copy);
+//   * everything is enqueued on one HIP stream, stage boundaries are HIP events; host-blocking per-stage timing is
+//     opt-in (DFFT_EXEC_SYNC_STAGES) for drop-in comparability with the reference's MPI_Wtime brackets.
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "dfft_internal.h"
+
+namespace dfft {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int  fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// twiddle tables
+struct TwKey {
+    int  dev, n, dtype;
+    bool operator<(const TwKey& o) const {
+        if (dev != o.dev) return dev < o.dev;
+        if (n != o.n) return n < o.n;
+        return dtype < o.dtype;
+    }
+};
+static std::mutex               g_tw_mutex;
+static std::map<TwKey, void*>   g_tw_cache;
+
+int get_twiddles(int n, int dtype, const void** table) {
+    int dev = 0;
+    DFFT_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_tw_mutex);
+    TwKey key{dev, n, dtype};
+    auto it = g_tw_cache.find(key);
+    if (it != g_tw_cache.end()) {
+        *table = it->second;
+        return DFFT_OK;
+    }
+    // e^{-2 pi i k / n} evaluated in extended precision and rounded once (the reference builds its LUT with host
+    // double cos/sin, templateFFT.cpp:5120-5141).
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    void*             dptr = nullptr;
+    if (dtype == DFFT_F64) {
+        std::vector<double> h(2 * (size_t)n);
+        for (int k = 0; k < n; ++k) {
+            const long double a = two_pi * (long double)k / (long double)n;
+            h[2 * k] = (double)cosl(a);
+            h[2 * k + 1] = (double)(-sinl(a));
+        }
+        DFFT_HIP_TRY(hipMalloc(&dptr, h.size() * sizeof(double)));
+        DFFT_HIP_TRY(hipMemcpy(dptr, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> h(2 * (size_t)n);
+        for (int k = 0; k < n; ++k) {
+            const long double a = two_pi * (long double)k / (long double)n;
+            h[2 * k] = (float)cosl(a);
+            h[2 * k + 1] = (float)(-sinl(a));
+        }
+        DFFT_HIP_TRY(hipMalloc(&dptr, h.size() * sizeof(float)));
+        DFFT_HIP_TRY(hipMemcpy(dptr, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    g_tw_cache[key] = dptr;
+    *table = dptr;
+    return DFFT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch helpers: the three passes expressed as address maps of the one FFT kernel template
+static AxisMap plain_axis(long long n, long long stride, long long cstride) {
+    AxisMap m;
+    m.blk = (int)n;
+    m.nblk = 1;
+    m.blk_stride = 0;
+    m.stride = stride;
+    m.cstride = cstride;
+    m.last_delta = 0;
+    return m;
+}
+
+static int check_launch(hipError_t e, const char* what) {
+    if (e == hipSuccess) return DFFT_OK;
+    if (e == hipErrorInvalidValue) return fail(DFFT_EUNSUPPORTED, std::string(what) + ": no gfx950 kernel for this length/precision");
+    return fail(DFFT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// contiguous rows: `rows` FFTs of length n, row pitch n
+static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s) {
+    const void* tw = nullptr;
+    int         rc = get_twiddles(n, dtype, &tw);
+    if (rc) return rc;
+    FftLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.dtype = dtype;
+    L.n = n;
+    L.dir = dir;
+    L.cols = 0;
+    L.in = in;
+    L.out = out;
+    L.tw = tw;
+    L.imap = L.omap = plain_axis(n, 1, 0);
+    L.itile = L.otile = TileMap{(long long)n, 0};
+    L.ntiles = rows;
+    L.tiles_per_a = 1;
+    L.ncols = 1;
+    return check_launch(launch_fft(L, s), "fft_rows");
+}
+
+}  // namespace dfft
+
+using namespace dfft;
+
+// ---------------------------------------------------------------------------------------------------------------
+struct dfft_plan_s {
+    long long   N[3];
+    int         dtype, direction;
+    int         P, me;
+    unsigned    flags;
+    bool        inplace, is_last;
+    long long   max_count;
+    Slab        sx, sy;       // X slabs (before), Y slabs (after)
+    long long   xs, ys;       // this device's extents
+    void *      in, *out, *buf1, *buf2;
+    dfft_comm_t comm;
+    int         device;
+    hipStream_t stream;
+    hipEvent_t  ev[5];
+    double      host_t[4];
+    bool        host_timed;
+    ExchangeDesc xd;
+    int         cb_y, cb_x;  // column-tile widths of the Y and X passes
+};
+
+static int fill_exchange(dfft_plan_s* p) {
+    const int       P = p->P, me = p->me;
+    const long long n2 = p->N[2];
+    ExchangeDesc&   x = p->xd;
+    x.dtype = p->dtype;
+    x.P = P;
+    x.me = me;
+    x.scount.assign(P, 0);
+    x.soffset.assign(P, 0);
+    x.rcount.assign(P, 0);
+    x.roffset.assign(P, 0);
+    x.doffset.assign(P, 0);
+    for (int q = 0; q < P; ++q) {
+        if (p->direction == DFFT_FORWARD) {
+            // chunk(me -> q) = x in me's slab, y in q's slab          
+            x.scount[q] = p->sx.size(me) * p->sy.size(q) * n2;
+            x.soffset[q] = (long long)q * p->sx.size(me) * p->sy.blk * n2;   // packed [d][xl][yl_d][N2]
+            x.rcount[q] = p->sx.size(q) * p->sy.size(me) * n2;
+            x.roffset[q] = p->sx.start(q) * p->sy.size(me) * n2;              // [x][yl_me][N2], x = q*xl + xi
+            x.doffset[q] = p->sx.start(me) * p->sy.size(q) * n2;
+        } else {
+            // chunk(me -> q) = x in q's slab, y in me's slab
+            x.scount[q] = p->sx.size(q) * p->sy.size(me) * n2;
+            x.soffset[q] = p->sx.start(q) * p->sy.size(me) * n2;
+            x.rcount[q] = p->sx.size(me) * p->sy.size(q) * n2;
+            x.roffset[q] = (long long)q * p->sx.size(me) * p->sy.blk * n2;
+            x.doffset[q] = (long long)me * p->sx.size(q) * p->sy.blk * n2;
+        }
+    }
+    return DFFT_OK;
+}
+
+// Y pass.  Natural side: [xs][N1][N2].  Packed side: [d][xs][yl_d][N2].
+static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_is_out, bool use_packed) {
+    const int       n1 = (int)p->N[1];
+    const long long n2 = p->N[2];
+    const void*     tw = nullptr;
+    int             rc = get_twiddles(n1, p->dtype, &tw);
+    if (rc) return rc;
+    const int cb = p->cb_y;
+    FftLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.dtype = p->dtype;
+    L.n = n1;
+    L.dir = p->direction;
+    L.cols = 1;
+    L.in = in;
+    L.out = out;
+    L.tw = tw;
+    AxisMap natural = plain_axis(n1, n2, 1);
+    TileMap nat_tile{(long long)n1 * n2, 1};
+    AxisMap packed;
+    packed.blk = (int)p->sy.blk;
+    packed.nblk = p->P;
+    packed.blk_stride = p->xs * p->sy.blk * n2;
+    packed.stride = n2;
+    packed.cstride = 1;
+    packed.last_delta = (p->sy.size(p->P - 1) - p->sy.blk) * n2;
+    TileMap pk_tile{p->sy.blk * n2, 1};
+    L.imap = natural;
+    L.itile = nat_tile;
+    L.omap = natural;
+    L.otile = nat_tile;
+    if (use_packed) {
+        if (packed_side_is_out) {
+            L.omap = packed;
+            L.otile = pk_tile;
+        } else {
+            L.imap = packed;
+            L.itile = pk_tile;
+        }
+    }
+    L.tiles_per_a = (int)((n2 + cb - 1) / cb);
+    L.ntiles = p->xs * L.tiles_per_a;
+    L.ncols = (int)n2;
+    return check_launch(launch_fft(L, p->stream), "Y pass");
+}
+
+// X pass.  Slab side: [N0][ys][N2] (x slowest).  Transposed side: [ys][N2][N0] (kx fastest).
+static int launch_x(dfft_plan_s* p, const void* in, void* out) {
+    const int       n0 = (int)p->N[0];
+    const long long n2 = p->N[2];
+    const void*     tw = nullptr;
+    int             rc = get_twiddles(n0, p->dtype, &tw);
+    if (rc) return rc;
+    const int cb = p->cb_x;
+    FftLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.dtype = p->dtype;
+    L.n = n0;
+    L.dir = p->direction;
+    L.cols = 1;
+    L.in = in;
+    L.out = out;
+    L.tw = tw;
+    AxisMap slab = plain_axis(n0, p->ys * n2, 1);
+    TileMap slab_tile{n2, 1};
+    AxisMap tr = plain_axis(n0, 1, n0);
+    TileMap tr_tile{n2 * (long long)n0, (long long)n0};
+    if (p->direction == DFFT_FORWARD) {
+        L.imap = slab;
+        L.itile = slab_tile;
+        L.omap = tr;
+        L.otile = tr_tile;
+    } else {
+        L.imap = tr;
+        L.itile = tr_tile;
+        L.omap = slab;
+        L.otile = slab_tile;
+    }
+    L.tiles_per_a = (int)((n2 + cb - 1) / cb);
+    L.ntiles = p->ys * L.tiles_per_a;
+    L.ncols = (int)n2;
+    return check_launch(launch_fft(L, p->stream), "X pass");
+}
+
+namespace {
+struct StageClock {
+    dfft_plan_s* p;
+    bool         sync;
+    int          idx = 0;
+    std::chrono::steady_clock::time_point t;
+    int begin() {
+        if (sync) {
+            DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
+            t = std::chrono::steady_clock::now();
+        } else {
+            DFFT_HIP_TRY(hipEventRecord(p->ev[0], p->stream));
+        }
+        return DFFT_OK;
+    }
+    int end_stage() {
+        if (sync) {
+            DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
+            auto now = std::chrono::steady_clock::now();
+            p->host_t[idx] = std::chrono::duration<double>(now - t).count();
+            t = now;
+        } else {
+            DFFT_HIP_TRY(hipEventRecord(p->ev[idx + 1], p->stream));
+        }
+        ++idx;
+        return DFFT_OK;
+    }
+};
+}  // namespace
+
+#define DFFT_TRY(stmt)        \
+    do {                      \
+        int rc_ = (stmt);     \
+        if (rc_) return rc_;  \
+    } while (0)
+
+static int execute_forward(dfft_plan_s* p, bool sync) {
+    const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
+    const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
+    StageClock      clk{p, sync};
+    DFFT_TRY(clk.begin());
+    // ---- t0: 2D YZ FFT of every owned plane ----
+    const void* zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
+    DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, p->xs * n1, p->dtype, p->direction, p->stream));
+    if (fused && p->P > 1) {
+        DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true));  // Y FFT + pack in one pass
+        DFFT_TRY(clk.end_stage());
+        DFFT_TRY(clk.end_stage());  // t1 folded into t0
+    } else {
+        DFFT_TRY(launch_y(p, p->buf1, p->buf1, true, false));
+        DFFT_TRY(clk.end_stage());
+        // ---- t1: pack ----
+        if (!fused) {
+            hipError_t e = launch_pack(p->dtype, +1, p->buf1, p->buf2, (int)p->xs, (int)n1, (int)n2, (int)p->sy.blk,
+                                       (int)p->sy.size(p->P - 1), p->P, p->stream);
+            if (e != hipSuccess) return fail(DFFT_EHIP, std::string("pack: ") + hipGetErrorString(e));
+        }
+        DFFT_TRY(clk.end_stage());
+    }
+    // ---- t2: exchange ----
+    const void* xsrc = p->buf1;
+    if (p->P > 1) {
+        DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));
+    } else if (!fused) {
+        // reference structure: full-size self copy bufferDev2 -> bufferDev1 (fft_mpi_3d_api.cpp:613-630)
+        DFFT_HIP_TRY(hipMemcpyAsync(p->buf1, p->buf2, (size_t)p->xs * n1 * n2 * elem_bytes(p->dtype),
+                                    hipMemcpyDeviceToDevice, p->stream));
+    }
+    DFFT_TRY(clk.end_stage());
+    // ---- t3: X FFT (+ transpose to [yl][N2][N0]) ----
+    if (fused) {
+        DFFT_TRY(launch_x(p, xsrc, p->buf2));
+    } else {
+        hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, n0, p->ys * n2, p->stream);
+        if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
+        DFFT_TRY(fft_rows(p->buf2, p->buf2, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream));
+    }
+    DFFT_TRY(clk.end_stage());
+    return DFFT_OK;
+}
+
+static int execute_backward(dfft_plan_s* p, bool sync) {
+    const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
+    const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
+    StageClock      clk{p, sync};
+    DFFT_TRY(clk.begin());
+    const void* src = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
+    // ---- inverse X FFT: [ys][N2][kx] -> [x][ys][N2] ----
+    if (fused) {
+        DFFT_TRY(launch_x(p, src, p->buf2));
+    } else {
+        DFFT_TRY(fft_rows(src, p->buf1, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream));
+        hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, p->ys * n2, n0, p->stream);
+        if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
+    }
+    DFFT_TRY(clk.end_stage());
+    // ---- exchange back ----
+    void* ybuf = p->buf2;  // where the Y/Z passes run
+    if (p->P > 1) {
+        DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));  // buf2 -> peers' buf1 (packed [d][xs][yl_d][N2])
+    } else if (!fused) {
+        DFFT_HIP_TRY(hipMemcpyAsync(p->buf1, p->buf2, (size_t)p->xs * n1 * n2 * elem_bytes(p->dtype),
+                                    hipMemcpyDeviceToDevice, p->stream));
+    }
+    DFFT_TRY(clk.end_stage());
+    // ---- unpack + inverse Y, inverse Z ----
+    if (fused) {
+        DFFT_TRY(clk.end_stage());  // unpack folded into the Y pass
+        if (p->P > 1) DFFT_TRY(launch_y(p, p->buf1, ybuf, false, true));
+        else DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false));
+    } else {
+        hipError_t e = launch_pack(p->dtype, -1, p->buf1, p->buf2, (int)p->xs, (int)n1, (int)n2, (int)p->sy.blk,
+                                   (int)p->sy.size(p->P - 1), p->P, p->stream);
+        if (e != hipSuccess) return fail(DFFT_EHIP, std::string("unpack: ") + hipGetErrorString(e));
+        DFFT_TRY(clk.end_stage());
+        DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false));
+    }
+    DFFT_TRY(fft_rows(ybuf, ybuf, (int)n2, p->xs * n1, p->dtype, p->direction, p->stream));
+    DFFT_TRY(clk.end_stage());
+    return DFFT_OK;
+}
+
+extern "C" {
+
+const char* dfft_version(void) { return "dfft-mi355x 0.1 (gfx950)"; }
+const char* dfft_last_error(void) { return g_last_error.c_str(); }
+
+int dfft_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int dfft_length_supported(long long n) { return (n > 0 && n < (1ll << 30) && fft_length_supported((int)n)) ? 1 : 0; }
+
+int dfft_proper_device_count(const long long N[3], int ini_devices_in_rank, int nranks, int rank, int real_devices,
+                             int* new_total, int* new_in_rank) {
+    if (!N || !new_total || !new_in_rank || nranks < 1 || rank < 0 || rank >= nranks || ini_devices_in_rank < 1)
+        return fail(DFFT_EINVAL, "dfft_proper_device_count: bad arguments");
+    int ini = ini_devices_in_rank;
+    if (real_devices >= 0 && ini > real_devices) ini = real_devices;  // fft_mpi_3d_api.cpp:236-239
+    if (ini < 1) return fail(DFFT_ENOGPU, "dfft_proper_device_count: no device available");
+    int total = ini * nranks, in_rank = ini;
+    if (N[0] % total != 0) {  // :244-259
+        const long long per = N[0] / total + 1;
+        total = (int)(N[0] / per);
+        if (N[0] % per != 0) total += 1;
+        in_rank = total / nranks;
+        const int rem = total % nranks;
+        if (rem != 0 && rank < rem) in_rank += 1;
+    }
+    *new_total = total;
+    *new_in_rank = in_rank;
+    if (in_rank == 0) return fail(DFFT_EINVAL, "could not support this distribution of data");  // :266-269
+    return DFFT_OK;
+}
+
+long long dfft_local_count(const long long N[3], int total_devices, int global_idx) {
+    if (!N || total_devices < 1 || global_idx < 0 || global_idx >= total_devices) return -1;
+    const Slab sx = make_slab(N[0], total_devices);
+    return sx.size(global_idx) * N[1] * N[2];
+}
+
+long long dfft_max_count(long long n0, long long n1, long long n2, int total_devices, int is_last_device) {
+    if (total_devices < 1) return -1;
+    const Slab      sx = make_slab(n0, total_devices), sy = make_slab(n1, total_devices);
+    const int       g = is_last_device ? total_devices - 1 : 0;
+    const long long a = sx.size(g) * n1 * n2, b = n0 * sy.size(g) * n2;
+    return a > b ? a : b;
+}
+
+int dfft_local_size(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long* local_n0,
+                    long long* local_0_start, long long* local_n1, long long* local_1_start) {
+    (void)n2;
+    if (total_devices < 1 || global_idx < 0 || global_idx >= total_devices)
+        return fail(DFFT_EINVAL, "dfft_local_size: bad arguments");
+    const Slab sx = make_slab(n0, total_devices), sy = make_slab(n1, total_devices);
+    if (local_n0) *local_n0 = sx.size(global_idx);
+    if (local_0_start) *local_0_start = sx.start(global_idx);
+    if (local_n1) *local_n1 = sy.size(global_idx);
+    if (local_1_start) *local_1_start = sy.start(global_idx);
+    return DFFT_OK;
+}
+
+int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
+                         long long* scount, long long* soffset, long long* rcount, long long* roffset) {
+    if (total_devices < 1 || global_idx < 0 || global_idx >= total_devices ||
+        (direction != DFFT_FORWARD && direction != DFFT_BACKWARD))
+        return fail(DFFT_EINVAL, "dfft_exchange_layout: bad arguments");
+    dfft_plan_s tmp;
+    tmp.N[0] = n0;
+    tmp.N[1] = n1;
+    tmp.N[2] = n2;
+    tmp.P = total_devices;
+    tmp.me = global_idx;
+    tmp.direction = direction;
+    tmp.dtype = DFFT_F64;
+    tmp.sx = make_slab(n0, total_devices);
+    tmp.sy = make_slab(n1, total_devices);
+    if (tmp.sx.size(total_devices - 1) < 1 || tmp.sy.size(total_devices - 1) < 1)
+        return fail(DFFT_EINVAL, "dfft_exchange_layout: last slab would be empty");
+    fill_exchange(&tmp);
+    for (int q = 0; q < total_devices; ++q) {
+        if (scount) scount[q] = tmp.xd.scount[q];
+        if (soffset) soffset[q] = tmp.xd.soffset[q];
+        if (rcount) rcount[q] = tmp.xd.rcount[q];
+        if (roffset) roffset[q] = tmp.xd.roffset[q];
+    }
+    return DFFT_OK;
+}
+
+void* dfft_alloc(long long count, int dtype, int flag) {
+    if (count < 0 || (dtype != DFFT_F64 && dtype != DFFT_F32)) {
+        set_error("dfft_alloc: bad arguments");
+        return nullptr;
+    }
+    const size_t bytes = (size_t)count * elem_bytes(dtype);
+    void*        p = nullptr;
+    if (flag == DFFT_ALLOC_HOST) {
+        p = malloc(bytes ? bytes : 1);
+    } else if (flag == DFFT_ALLOC_DEV) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            return nullptr;
+        }
+    } else {
+        set_error("Fail to allocate memory!");  // fft_mpi_3d_api.cpp:226
+    }
+    return p;
+}
+
+int dfft_free(void* p, int flag) {
+    if (!p) return DFFT_OK;
+    if (flag == DFFT_ALLOC_HOST) {
+        free(p);
+        return DFFT_OK;
+    }
+    DFFT_HIP_TRY(hipFree(p));
+    return DFFT_OK;
+}
+
+int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2, int dtype, int direction, void* in,
+                     void* out, dfft_comm_t comm, int global_idx, int total_devices, unsigned flags) {
+    if (!plan || !in) return fail(DFFT_EINVAL, "dfft_plan_create: null plan/in");
+    if (n0 < 1 || n1 < 1 || n2 < 1) return fail(DFFT_EINVAL, "dfft_plan_create: sizes must be positive");
+    if (dtype != DFFT_F64 && dtype != DFFT_F32) return fail(DFFT_EINVAL, "dfft_plan_create: dtype");
+    if (direction != DFFT_FORWARD && direction != DFFT_BACKWARD) return fail(DFFT_EINVAL, "dfft_plan_create: direction");
+    if (total_devices < 1 || global_idx < 0 || global_idx >= total_devices)
+        return fail(DFFT_EINVAL, "dfft_plan_create: device index");
+    if (total_devices > 1 && !comm) return fail(DFFT_EINVAL, "dfft_plan_create: a communicator is required for P > 1");
+    if (comm && comm_size(comm) != total_devices) return fail(DFFT_EINVAL, "dfft_plan_create: communicator size != P");
+    if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_plan_create: no HIP device visible (no CPU fallback)");
+    for (long long n : {n0, n1, n2})
+        if (!dfft_length_supported(n))
+            return fail(DFFT_EUNSUPPORTED, "dfft_plan_create: FFT length " + std::to_string(n) + " has no gfx950 plan");
+
+    dfft_plan_s* p = new dfft_plan_s;
+    p->N[0] = n0;
+    p->N[1] = n1;
+    p->N[2] = n2;
+    p->dtype = dtype;
+    p->direction = direction;
+    p->P = total_devices;
+    p->me = global_idx;
+    p->flags = flags;
+    p->is_last = (global_idx == total_devices - 1);
+    p->sx = make_slab(n0, total_devices);
+    p->sy = make_slab(n1, total_devices);
+    p->xs = p->sx.size(global_idx);
+    p->ys = p->sy.size(global_idx);
+    p->comm = comm;
+    p->host_timed = false;
+    for (double& t : p->host_t) t = 0;
+    if (p->sx.size(total_devices - 1) < 1 || p->sy.size(total_devices - 1) < 1) {
+        delete p;
+        return fail(DFFT_EINVAL, "dfft_plan_create: slab decomposition leaves the last device empty");
+    }
+    p->max_count = dfft_max_count(n0, n1, n2, total_devices, p->is_last);
+    if (p->max_count >= (1ll << 31)) {
+        delete p;
+        return fail(DFFT_EUNSUPPORTED, "dfft_plan_create: more than 2^31 elements per device");
+    }
+    p->in = in;
+    p->out = out;
+    p->inplace = (out == nullptr || out == in);  // fft_mpi_3d_api.cpp:68-75
+    p->buf2 = p->inplace ? in : out;
+    if (p->inplace && (flags & DFFT_PLAN_INPUT_FROM_IN)) {
+        delete p;
+        return fail(DFFT_EINVAL, "dfft_plan_create: DFFT_PLAN_INPUT_FROM_IN needs an out-of-place plan");
+    }
+    p->cb_y = fft_cols_per_tile(dtype, (int)n1);
+    p->cb_x = fft_cols_per_tile(dtype, (int)n0);
+    p->buf1 = nullptr;
+    p->stream = nullptr;
+    for (auto& e : p->ev) e = nullptr;
+    const size_t bytes = (size_t)p->max_count * elem_bytes(dtype);
+    hipError_t   e = hipGetDevice(&p->device);
+    if (e == hipSuccess) e = hipMalloc(&p->buf1, bytes);
+    if (e == hipSuccess) e = hipMemcpy(p->buf1, in, bytes, hipMemcpyDeviceToDevice);  // :77 input captured at plan time
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    for (auto& ev : p->ev)
+        if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e != hipSuccess) {
+        dfft_plan_destroy(p);
+        return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+    }
+    fill_exchange(p);
+    p->xd.sendbuf = p->buf2;
+    p->xd.recvbuf = p->buf1;
+    if (comm) {
+        int rc = comm_register(comm, global_idx, p->buf1, p->device);  // nodeDataDev[loc] = bufferDev1, :80
+        if (rc) {
+            dfft_plan_destroy(p);
+            return rc;
+        }
+    }
+    // warm the twiddle caches so execute never allocates
+    for (long long n : {n0, n1, n2}) {
+        const void* tw;
+        int         rc = get_twiddles((int)n, dtype, &tw);
+        if (rc) {
+            dfft_plan_destroy(p);
+            return rc;
+        }
+    }
+    *plan = p;
+    return DFFT_OK;
+}
+
+void* dfft_plan_buffer1(dfft_plan_t plan) { return plan ? plan->buf1 : nullptr; }
+void* dfft_plan_result(dfft_plan_t plan) { return plan ? plan->buf2 : nullptr; }
+void* dfft_plan_stream(dfft_plan_t plan) { return plan ? (void*)plan->stream : nullptr; }
+
+int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
+    if (!plan) return fail(DFFT_EINVAL, "dfft_execute: null plan");
+    const bool sync = (exec_flags & DFFT_EXEC_SYNC_STAGES) != 0;
+    plan->host_timed = sync;
+    int rc = plan->direction == DFFT_FORWARD ? execute_forward(plan, sync) : execute_backward(plan, sync);
+    if (rc) return rc;
+    if ((exec_flags & DFFT_EXEC_PRINT) && plan->direction == DFFT_FORWARD) {
+        double t[4];
+        rc = dfft_stage_times(plan, t);
+        if (rc) return rc;
+        // fft_mpi_3d_api.cpp:201
+        printf("t0: %lf, t1: %lf, t2: %lf, t3: %lf, total: %lf\n", t[0], t[1], t[2], t[3], t[0] + t[1] + t[2] + t[3]);
+    }
+    return DFFT_OK;
+}
+
+int dfft_plan_sync(dfft_plan_t plan) {
+    if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
+    DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    return DFFT_OK;
+}
+
+int dfft_stage_times(dfft_plan_t plan, double t[4]) {
+    if (!plan || !t) return fail(DFFT_EINVAL, "dfft_stage_times: bad arguments");
+    DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    if (plan->host_timed) {
+        for (int i = 0; i < 4; ++i) t[i] = plan->host_t[i];
+        return DFFT_OK;
+    }
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0;
+        DFFT_HIP_TRY(hipEventElapsedTime(&ms, plan->ev[i], plan->ev[i + 1]));
+        t[i] = ms * 1e-3;
+    }
+    return DFFT_OK;
+}
+
+int dfft_plan_destroy(dfft_plan_t plan) {
+    if (!plan) return DFFT_OK;
+    if (plan->stream) hipStreamSynchronize(plan->stream);
+    if (plan->comm) comm_unregister(plan->comm, plan->me);
+    for (auto& e : plan->ev)
+        if (e) hipEventDestroy(e);
+    if (plan->stream) hipStreamDestroy(plan->stream);
+    if (plan->buf1) hipFree(plan->buf1);
+    delete plan;
+    return DFFT_OK;
+}
+
+int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype, int direction, void* stream) {
+    if (!in || !out || batch < 0) return fail(DFFT_EINVAL, "dfft_fft1d_rows: bad arguments");
+    if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_rows: unsupported length");
+    if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_rows: no HIP device visible (no CPU fallback)");
+    return fft_rows(in, out, (int)n, batch, dtype, direction, (hipStream_t)stream);
+}
+
+int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
+                    void* stream) {
+    if (!in || !out || batch < 0 || width < 1) return fail(DFFT_EINVAL, "dfft_fft1d_cols: bad arguments");
+    if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_cols: unsupported length");
+    if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_cols: no HIP device visible (no CPU fallback)");
+    const void* tw = nullptr;
+    int         rc = get_twiddles((int)n, dtype, &tw);
+    if (rc) return rc;
+    const int cb = fft_cols_per_tile(dtype, (int)n);
+    FftLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.dtype = dtype;
+    L.n = (int)n;
+    L.dir = direction;
+    L.cols = 1;
+    L.in = in;
+    L.out = out;
+    L.tw = tw;
+    L.imap = L.omap = plain_axis(n, width, 1);
+    L.itile = L.otile = TileMap{n * width, 1};
+    L.tiles_per_a = (int)((width + cb - 1) / cb);
+    L.ntiles = batch * L.tiles_per_a;
+    L.ncols = (int)width;
+    return check_launch(launch_fft(L, (hipStream_t)stream), "dfft_fft1d_cols");
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+// dfft_plans.h -- compile-time radix plans (N, points per thread E, radix sequence), largest radix first.
+//
+// Takes over the *decisions* of the reference's run-time scheduler (templateFFT.cpp:3941-4607 FFTScheduler:
+// fold 2s into radix 8 then 4, largest radix first, 8 complex registers per thread for powers of two,
+// 12/24 when a factor 3 is present) as a static table; nothing is generated at run time.
+// X(N, group, E, radices...) -- "group" only spreads the instantiations over translation units.
+#pragma once
+
+#define DFFT_PLAN_TABLE(X)        \
+    X(2, 0, 2, 2)                 \
+    X(3, 0, 3, 3)                 \
+    X(4, 0, 4, 4)                 \
+    X(5, 0, 5, 5)                 \
+    X(6, 0, 6, 3, 2)              \
+    X(8, 0, 8, 8)                 \
+    X(9, 0, 3, 3, 3)              \
+    X(10, 0, 10, 5, 2)            \
+    X(12, 0, 12, 4, 3)            \
+    X(16, 0, 4, 4, 4)             \
+    X(24, 0, 24, 8, 3)            \
+    X(25, 0, 5, 5, 5)             \
+    X(32, 1, 8, 8, 4)             \
+    X(48, 1, 24, 8, 3, 2)         \
+    X(64, 1, 8, 8, 8)             \
+    X(96, 1, 24, 8, 4, 3)         \
+    X(100, 1, 20, 5, 5, 4)        \
+    X(125, 1, 5, 5, 5, 5)         \
+    X(128, 2, 8, 8, 8, 2)         \
+    X(192, 2, 24, 8, 8, 3)        \
+    X(256, 2, 8, 8, 8, 4)         \
+    X(384, 3, 24, 8, 8, 3, 2)     \
+    X(512, 3, 8, 8, 8, 8)         \
+    X(768, 4, 24, 8, 8, 4, 3)     \
+    X(1024, 5, 8, 8, 8, 8, 2)     \
+    X(2048, 6, 16, 8, 8, 8, 4)
+
+#define DFFT_NUM_INST_GROUPS 7

@@ -1,0 +1,148 @@
+/* dfft.h -- C-ABI of libdfft_mi355x.so: the MI355X-native slab 3D C2C FFT.
+ *
+ * This is the drop-in boundary for the hot path of lueelu/DistributedFFT's 3dmpifft_opt
+ * (t0 batched 2D YZ FFT -> t1 pack -> t2 all-to-all -> t3 batched 1D X FFT).  Every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/3dmpifft_opt/include/).  The reference API has C++ linkage
+ * (fft_mpi_3d_api.h:68-79); thin C++ wrappers with the original names live in include/fft_mpi_3d_api.h and call
+ * straight into these functions, so the reference driver (fftSpeed3d_c2c.cpp) recompiles unchanged against this
+ * library.  Plain pointers and sizes only: no torch, no MPI, no C++ types in any signature.
+ *
+ * Error handling: functions returning int return 0 on success and a negative DFFT_E* code on failure (the C++
+ * wrappers reproduce the reference behaviour: print "[file:line] ... failed" and exit(EXIT_FAILURE),
+ * fft_mpi_common.h:31-103).  dfft_last_error() returns a thread-local message for the last failure.
+ *
+ * Layout contract, device g of P, xl = ceil(N0/P), yl = ceil(N1/P), last device takes the rest:
+ *   forward  input  : [x_local][N1][N2]  (x slowest)            element (xi*N1 + y)*N2 + z
+ *   forward  output : [y_local][N2][N0]  (kx fastest)           element (yy*N2 + z)*N0 + kx   (transposed, Y-slabbed)
+ *   backward input  : the forward output layout;  backward output: the forward input layout.  Both unnormalised.
+ */
+#ifndef DFFT_H
+#define DFFT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFFT_FORWARD 1   /* fft_mpi_common.h:18  FORWARD  */
+#define DFFT_BACKWARD (-1) /* fft_mpi_common.h:19  BACKWARD */
+#define DFFT_ALLOC_HOST 1  /* fft_mpi_common.h:15  ALLOC_CPU */
+#define DFFT_ALLOC_DEV (-1) /* fft_mpi_common.h:16  ALLOC_DEV */
+
+#define DFFT_F64 0 /* Complex = double[2] (fft_mpi_common.h:21); the only precision the reference has */
+#define DFFT_F32 1 /* float[2]; BASELINE config 5 */
+
+/* error codes */
+#define DFFT_OK 0
+#define DFFT_EINVAL (-1)      /* bad argument / unsupported size */
+#define DFFT_EHIP (-2)        /* a HIP runtime call failed */
+#define DFFT_ERCCL (-3)       /* an RCCL call failed */
+#define DFFT_ENOGPU (-4)      /* no usable gfx950 device: the product path has no CPU fallback */
+#define DFFT_ECOMM (-5)       /* bootstrap / rendezvous failure */
+#define DFFT_EUNSUPPORTED (-6)
+
+/* plan flags */
+#define DFFT_PLAN_DEFAULT 0u
+#define DFFT_PLAN_UNFUSED 1u        /* reference stage structure: Y-FFT in place, separate pack (t1), separate tile transpose
+                                       in t3.  Default is fused (pack and transpose folded into the FFT kernels' stores). */
+#define DFFT_PLAN_INPUT_FROM_IN 2u  /* every execute re-reads the caller's `in` (first pass runs out-of-place in -> bufferDev1)
+                                       instead of consuming bufferDev1; out-of-place plans only.  Same HBM traffic. */
+#define DFFT_PLAN_OVERLAP 4u        /* P > 1: split the exchange in sub-slabs and overlap t2 with t3 on a second stream */
+
+/* execute flags */
+#define DFFT_EXEC_ASYNC 0u          /* enqueue on the plan's stream and return */
+#define DFFT_EXEC_SYNC_STAGES 1u    /* hipDeviceSynchronize-style host timing per stage, like fft_mpi_3d_api.cpp:184-201 */
+#define DFFT_EXEC_PRINT 2u          /* print the reference's "t0: .. t1: .. t2: .. t3: .. total: .." line (forward only) */
+
+typedef struct dfft_plan_s* dfft_plan_t;
+typedef struct dfft_comm_s* dfft_comm_t;
+
+/* ---- library / device ------------------------------------------------------------------------------------------ */
+const char* dfft_version(void);
+const char* dfft_last_error(void);
+/* Number of visible HIP devices (0 if none).  hipGetDeviceCount in fftSpeed3d_c2c.cpp:33-34. */
+int dfft_device_count(void);
+/* 1 if FFT length n has a compiled gfx950 plan (radix 2/3/4/5/8 products listed in csrc/dfft_plans.h). */
+int dfft_length_supported(long long n);
+
+/* ---- slab bookkeeping: pure host arithmetic, callable without a GPU ------------------------------------------------ */
+/* getProperDeviceNum (fft_mpi_3d_api.cpp:232-272): shrink the device count when N0 % P != 0 so every device but the
+ * last owns ceil(N0/P) planes.  real_devices < 0 skips the clamp to the visible device count. */
+int dfft_proper_device_count(const long long N[3], int ini_devices_in_rank, int nranks, int rank, int real_devices,
+                             int* new_total, int* new_in_rank);
+/* getDataCountForNode (fft_mpi_3d_api.cpp:274-287): elements held by global device idx before the transform. */
+long long dfft_local_count(const long long N[3], int total_devices, int global_idx);
+/* getMaxDataCount (fft_mpi_3d_api.cpp:289-316): elements each of in/out/bufferDev1 must hold. */
+long long dfft_max_count(long long n0, long long n1, long long n2, int total_devices, int is_last_device);
+/* Per-peer exchange counts/offsets in elements (tInfo, fft_mpi_3d_api.cpp:84-133; receive offsets :618-625).
+ * Arrays have total_devices entries.  direction = DFFT_FORWARD or DFFT_BACKWARD. */
+int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
+                         long long* scount, long long* soffset, long long* rcount, long long* roffset);
+/* local extents: x planes owned before / y rows owned after the forward transform, and their global starts.
+ * (the declared-but-never-defined fft_mpi_local_size_3d, fft_mpi_3d_api.h:73) */
+int dfft_local_size(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long* local_n0,
+                    long long* local_0_start, long long* local_n1, long long* local_1_start);
+
+/* ---- exchange communicators (t2) -------------------------------------------------------------------------------------
+ * LOCAL : all P devices are driven by threads of this process (reference: OpenMP thread per GPU + hipMemcpyPeerAsync,
+ *         fft_mpi_3d_api.cpp:613-630).  Also serves P "virtual" devices sharing one physical GPU (parity tests).
+ * RCCL  : one communicator rank per device, any process layout; replaces the MPI_Isend/Irecv on device pointers
+ *         (fft_mpi_3d_api.cpp:635-672) with grouped ncclSend/ncclRecv over xGMI. */
+int dfft_comm_create_local(int total_devices, dfft_comm_t* comm);
+/* 128-byte RCCL unique id; rank 0 creates it and the host distributes it (torch.distributed, MPI, dfft_boot_*). */
+int dfft_rccl_unique_id(char id[128]);
+int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx, dfft_comm_t* comm);
+int dfft_comm_destroy(dfft_comm_t comm);
+
+/* ---- memory ------------------------------------------------------------------------------------------------------------
+ * fft_mpi_alloc_local_memory (fft_mpi_3d_api.cpp:216-230); count in complex elements of dtype. */
+void* dfft_alloc(long long count, int dtype, int flag);
+int dfft_free(void* p, int flag);
+
+/* ---- plan / execute ------------------------------------------------------------------------------------------------------
+ * fft_mpi_plan_dft_c2c_3d (fft_mpi_3d_api.cpp:41-141).  `in`/`out` are device buffers of dfft_max_count elements owned
+ * by the caller; out == NULL or out == in selects in-place (bufferDev2 = in).  The plan allocates bufferDev1 and copies
+ * `in` into it (input is captured at plan time or by writing dfft_plan_buffer1()).  comm may be NULL when
+ * total_devices == 1.  The calling thread's current HIP device is the plan's device. */
+int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2, int dtype, int direction, void* in,
+                     void* out, dfft_comm_t comm, int global_idx, int total_devices, unsigned flags);
+/* plan->bufferDev1, which the reference driver writes directly (fftSpeed3d_c2c.cpp:78). */
+void* dfft_plan_buffer1(dfft_plan_t plan);
+/* the buffer holding the result after execute (bufferDev2 = out, or in when in-place). */
+void* dfft_plan_result(dfft_plan_t plan);
+void* dfft_plan_stream(dfft_plan_t plan); /* hipStream_t the plan enqueues on */
+/* fft_mpi_execute_dft_3d_c2c (fft_mpi_3d_api.cpp:181-214).  Collective over all devices of the communicator. */
+int dfft_execute(dfft_plan_t plan, unsigned exec_flags);
+/* Wait for the plan's stream. */
+int dfft_plan_sync(dfft_plan_t plan);
+/* Stage times of the last forward/backward execute in seconds: t[0..3] = t0..t3 (backward: X, exchange, unpack, YZ),
+ * from HIP events on the plan's stream (ASYNC) or host clocks (SYNC_STAGES).  Syncs the stream. */
+int dfft_stage_times(dfft_plan_t plan, double t[4]);
+/* fft_mpi_destroy_plan (fft_mpi_3d_api.cpp:143-179). */
+int dfft_plan_destroy(dfft_plan_t plan);
+
+/* ---- batched 1D building block (the kernels behind t0/t3; templateFFT batchTest-style checks) ---------------------------
+ * In-place or out-of-place length-n C2C FFT of `batch` contiguous rows (stride n). */
+int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype, int direction, void* stream);
+/* Length-n FFT down the columns of a [n][width] row-major matrix, `batch` matrices back to back. */
+int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
+                    void* stream);
+
+/* ---- tiny TCP rendezvous for multi-process launches without MPI ----------------------------------------------------------
+ * Replaces what the reference driver needs from MPI besides moving data (MPI_Comm_rank/size, MPI_Bcast of the RCCL id,
+ * MPI_Barrier, MPI_Reduce(MAX), fftSpeed3d_c2c.cpp:18-26,120-124).  Rank/size/address come from the environment:
+ * DFFT_RANK/DFFT_WORLD_SIZE/DFFT_MASTER_ADDR/DFFT_MASTER_PORT, else torchrun's RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT,
+ * else a PMI/OpenMPI launcher's PMI_RANK/PMI_SIZE or OMPI_COMM_WORLD_RANK/SIZE; single process if none is set. */
+int dfft_boot_init(void);
+int dfft_boot_rank(void);
+int dfft_boot_size(void);
+int dfft_boot_bcast(void* buf, size_t bytes, int root);
+int dfft_boot_barrier(void);
+int dfft_boot_allreduce_max(double* v, int n);
+int dfft_boot_finalize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFFT_H */

@@ -1,0 +1,216 @@
+// fft_mpi_3d_api.h -- the reference's distributed-FFT API names (C++ linkage, as in
+// /root/reference/3dmpifft_opt/include/fft_mpi_3d_api.h:68-86) as thin inline wrappers over the C-ABI of
+// libdfft_mi355x.so (include/dfft.h).  The reference driver fftSpeed3d_c2c.cpp compiles unchanged against this header:
+// same function names, argument meaning, plan member it pokes (plan->bufferDev1, fftSpeed3d_c2c.cpp:78), collective
+// calling discipline (one host thread per local GPU) and error behaviour (print + exit, fft_mpi_common.h:31-103).
+//
+// Header-only on purpose: MPI_Comm is whatever <mpi.h> the application was built with (a real MPI, or
+// include/dfft_mpi_shim/mpi.h), so no MPI type crosses the shared library's ABI.
+#ifndef __FFT_MPI_3D_API_H__
+#define __FFT_MPI_3D_API_H__
+
+#include <mutex>
+#include <vector>
+
+#include "fft_mpi_common.h"
+
+typedef struct fft_mpi_3d_plan {
+    // members of the reference struct (fft_mpi_3d_api.h:11-66) that describe the plan; the rocFFT/hipFFT/templateFFT
+    // handles have no counterpart here.
+    int         N[3];
+    int         locGPUIdx, devCountInNode, totalDevCount, globalDevIdx;
+    int         mpiRank, mpiSize;
+    bool        isLastDevice, isInplace;
+    longInt64   maxDataCountInDevice;
+    Complex *   inDev, *outDev, *bufferDev1, *bufferDev2, **nodeDataDev;
+    TransInfo   tInfo;
+    longInt64   lastExchangeN0, lastExchangeN1, lastExchangeN2;
+    hipStream_t stream1;
+    int         direction;
+    dfft_plan_t handle;  // the MI355X-native plan
+} * fft_mpi_3d_plan_p;
+
+namespace dfft_api_detail {
+// Process-wide state established by fft_mpi_init and consumed by plan creation (the reference keeps the equivalent
+// in the caller's node_data[] array plus OpenMP's implicit team, fft_mpi_3d_api.cpp:80,190).
+struct State {
+    std::mutex               m;
+    int                      total = 1, in_rank = 1, mpi_rank = 0, mpi_size = 1;
+    bool                     have_id = false;
+    char                     rccl_id[128];
+    dfft_comm_t              local = nullptr;          // single-process: shared by all device threads
+    std::vector<dfft_comm_t> rccl;                     // multi-process: one communicator rank per local device
+};
+inline State& state() {
+    static State s;
+    return s;
+}
+inline int first_dev_of_rank(int total, int mpi_size, int mpi_rank) {
+    return mpi_rank * (int)ceil((double)total / mpi_size);  // fft_mpi_3d_api.cpp:57
+}
+}  // namespace dfft_api_detail
+
+// getMaxDataCount (fft_mpi_3d_api.cpp:289-316)
+inline longInt64 getMaxDataCount(int n0, int n1, int n2, int totalDevCount, bool isLastDevice) {
+    return dfft_max_count(n0, n1, n2, totalDevCount, isLastDevice ? 1 : 0);
+}
+
+// fft_mpi_init (fft_mpi_3d_api.cpp:3-39): device-count fix-up, per-device element counts, exchange set-up.
+// Environment: DFFT_VIRTUAL_DEVICES=1 lets GPU_COUNT exceed the visible device count (devices are then shared
+// round-robin exactly as the reference driver's hipSetDevice(globalIdx % devCount), fftSpeed3d_c2c.cpp:53).
+inline void fft_mpi_init(const longInt64* N, int iniDeviceNumInNode, MPI_Comm comm, int& newDeviceCount,
+                         int& newDeviceCountInNode, longInt64 dataCountInNode[]) {
+    using namespace dfft_api_detail;
+    int mpi_size, mpi_rank;
+    MPI_CHECK(MPI_Comm_size(comm, &mpi_size));
+    MPI_CHECK(MPI_Comm_rank(comm, &mpi_rank));
+    int         real = dfft_device_count();
+    const char* virt = getenv("DFFT_VIRTUAL_DEVICES");
+    const bool  allow_virtual = virt && atoi(virt) != 0;
+    if (iniDeviceNumInNode > real && !allow_virtual) {
+        printf("The number of GPUs in rank %d is less than %d, so it will be set to %d (equal to your real device count).\n",
+               mpi_rank, iniDeviceNumInNode, real);  // fft_mpi_3d_api.cpp:237
+    }
+    DFFT_CHECK(dfft_proper_device_count(N, iniDeviceNumInNode, mpi_size, mpi_rank, allow_virtual ? -1 : real,
+                                        &newDeviceCount, &newDeviceCountInNode));
+    printf("allocate %d devices to node %d\n", newDeviceCountInNode, mpi_rank);  // :270
+    const int first = first_dev_of_rank(newDeviceCount, mpi_size, mpi_rank);
+    for (int i = 0; i < newDeviceCountInNode; ++i) {
+        dataCountInNode[i] = dfft_local_count(N, newDeviceCount, first + i);
+        printf("data count in device %d of node %d: %lld\n", i, mpi_rank, dataCountInNode[i]);  // :285
+    }
+    State& s = state();
+    std::lock_guard<std::mutex> lk(s.m);
+    s.total = newDeviceCount;
+    s.in_rank = newDeviceCountInNode;
+    s.mpi_rank = mpi_rank;
+    s.mpi_size = mpi_size;
+    if (s.local) {
+        dfft_comm_destroy(s.local);
+        s.local = nullptr;
+    }
+    s.rccl.assign(newDeviceCountInNode, nullptr);
+    s.have_id = false;
+    if (newDeviceCount > 1) {
+        if (mpi_size == 1) {
+            DFFT_CHECK(dfft_comm_create_local(newDeviceCount, &s.local));
+        } else {
+            // the reference's dead ENABLE_RCCL branch (fft_mpi_3d_api.cpp:29-37) made live
+            if (mpi_rank == 0) DFFT_CHECK(dfft_rccl_unique_id(s.rccl_id));
+            MPI_CHECK(MPI_Bcast(s.rccl_id, 128, MPI_BYTE, 0, comm));
+            s.have_id = true;
+        }
+    }
+}
+
+// fft_mpi_alloc_local_memory (fft_mpi_3d_api.cpp:216-230)
+inline Complex* fft_mpi_alloc_local_memory(int count, int flag) {
+    if (flag != ALLOC_CPU && flag != ALLOC_DEV) {
+        printf("Fail to allocate memory!\n");
+        exit(EXIT_FAILURE);
+    }
+    void* p = dfft_alloc(count, DFFT_F64, flag);
+    if (!p) {
+        fprintf(stderr, "[%s:%d] allocation of %d elements failed: %s\n", __FILE__, __LINE__, count, dfft_last_error());
+        exit(EXIT_FAILURE);
+    }
+    return (Complex*)p;
+}
+
+// fft_mpi_plan_dft_c2c_3d (fft_mpi_3d_api.cpp:41-141).  The calling thread's current HIP device owns the plan.
+inline fft_mpi_3d_plan_p fft_mpi_plan_dft_c2c_3d(longInt64 n0, longInt64 n1, longInt64 n2, Complex* in, Complex* out,
+                                                 Complex** node_data, MPI_Comm comm, int devIdx, int devCountInNode,
+                                                 int totalDevCount, int direction) {
+    using namespace dfft_api_detail;
+    fft_mpi_3d_plan_p plan = new fft_mpi_3d_plan;
+    plan->N[0] = (int)n0;
+    plan->N[1] = (int)n1;
+    plan->N[2] = (int)n2;
+    plan->direction = direction;
+    plan->locGPUIdx = devIdx;
+    plan->devCountInNode = devCountInNode;
+    plan->totalDevCount = totalDevCount;
+    MPI_CHECK(MPI_Comm_rank(comm, &plan->mpiRank));
+    MPI_CHECK(MPI_Comm_size(comm, &plan->mpiSize));
+    plan->globalDevIdx = first_dev_of_rank(totalDevCount, plan->mpiSize, plan->mpiRank) + devIdx;
+    plan->isLastDevice = (plan->globalDevIdx == totalDevCount - 1);
+    plan->maxDataCountInDevice = getMaxDataCount((int)n0, (int)n1, (int)n2, totalDevCount, plan->isLastDevice);
+    plan->inDev = in;
+    plan->outDev = out;
+    plan->isInplace = (out == NULL || out == in);
+    plan->lastExchangeN2 = n2;
+    plan->lastExchangeN0 = n0 - (totalDevCount - 1) * (longInt64)ceil((double)n0 / totalDevCount);
+    plan->lastExchangeN1 = n1 - (totalDevCount - 1) * (longInt64)ceil((double)n1 / totalDevCount);
+
+    dfft_comm_t c = nullptr;
+    if (totalDevCount > 1) {
+        State& s = state();
+        std::lock_guard<std::mutex> lk(s.m);
+        if (s.local) {
+            c = s.local;
+        } else {
+            if (!s.have_id || devIdx >= (int)s.rccl.size()) {
+                fprintf(stderr, "[%s:%d] fft_mpi_init must run before plan creation\n", __FILE__, __LINE__);
+                exit(EXIT_FAILURE);
+            }
+            if (!s.rccl[devIdx]) DFFT_CHECK(dfft_comm_create_rccl(s.rccl_id, totalDevCount, plan->globalDevIdx, &s.rccl[devIdx]));
+            c = s.rccl[devIdx];
+        }
+    }
+    DFFT_CHECK(dfft_plan_create(&plan->handle, n0, n1, n2, DFFT_F64, direction, in, out, c, plan->globalDevIdx,
+                                totalDevCount, DFFT_PLAN_DEFAULT));
+    plan->bufferDev1 = (Complex*)dfft_plan_buffer1(plan->handle);
+    plan->bufferDev2 = (Complex*)dfft_plan_result(plan->handle);
+    plan->stream1 = (hipStream_t)dfft_plan_stream(plan->handle);
+    plan->nodeDataDev = node_data;
+    if (node_data) node_data[devIdx] = plan->bufferDev1;  // fft_mpi_3d_api.cpp:80
+    plan->tInfo.rcount = new longInt64[totalDevCount];
+    plan->tInfo.roffset = new longInt64[totalDevCount];
+    plan->tInfo.scount = new longInt64[totalDevCount];
+    plan->tInfo.soffset = new longInt64[totalDevCount];
+    DFFT_CHECK(dfft_exchange_layout(n0, n1, n2, totalDevCount, plan->globalDevIdx, direction, plan->tInfo.scount,
+                                    plan->tInfo.soffset, plan->tInfo.rcount, plan->tInfo.roffset));
+    return plan;
+}
+
+// fft_mpi_execute_dft_3d_c2c (fft_mpi_3d_api.cpp:181-214): blocking, stage-timed, prints the "t0: ..." line on forward.
+inline void fft_mpi_execute_dft_3d_c2c(fft_mpi_3d_plan_p p) {
+    DFFT_CHECK(dfft_execute(p->handle, DFFT_EXEC_SYNC_STAGES | DFFT_EXEC_PRINT));
+}
+
+// fft_mpi_destroy_plan (fft_mpi_3d_api.cpp:143-179)
+inline void fft_mpi_destroy_plan(fft_mpi_3d_plan_p plan) {
+    delete[] plan->tInfo.rcount;
+    delete[] plan->tInfo.scount;
+    delete[] plan->tInfo.roffset;
+    delete[] plan->tInfo.soffset;
+    DFFT_CHECK(dfft_plan_destroy(plan->handle));
+    delete plan;
+}
+
+// Declared by the reference but never defined there (fft_mpi_3d_api.h:69,73); provided here.
+inline void fft_mpi_cleanup(void) {
+    using namespace dfft_api_detail;
+    State& s = state();
+    std::lock_guard<std::mutex> lk(s.m);
+    if (s.local) dfft_comm_destroy(s.local);
+    s.local = nullptr;
+    for (auto& c : s.rccl) {
+        if (c) dfft_comm_destroy(c);
+        c = nullptr;
+    }
+}
+inline longInt64 fft_mpi_local_size_3d(longInt64 n0, longInt64 n1, longInt64 n2, MPI_Comm comm, longInt64* local_n0,
+                                       longInt64* local_0_start) {
+    using namespace dfft_api_detail;
+    int rank, size;
+    MPI_CHECK(MPI_Comm_rank(comm, &rank));
+    MPI_CHECK(MPI_Comm_size(comm, &size));
+    State& s = state();
+    const int total = s.total > 0 ? s.total : size;
+    const int g = first_dev_of_rank(total, size, rank);
+    DFFT_CHECK(dfft_local_size(n0, n1, n2, total, g, local_n0, local_0_start, nullptr, nullptr));
+    return dfft_max_count(n0, n1, n2, total, g == total - 1);
+}
+
+#endif  // __FFT_MPI_3D_API_H__
