@@ -1,0 +1,253 @@
+"""bench.py -- the graded measurement of the hot path: forward 3D C2C FFT, 512^3 fp64, slab-decomposed over N GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one forward transform (t0 YZ FFT -> t1 pack -> t2 RCCL all-to-all -> t3 X FFT) of the same device-resident
+synthetic input (uniform [-1,1) re/im, seeded); the total problem is fixed at 512^3 (strong scaling: BASELINE.json quotes
+512^3 at 1/2/4/8 GPUs).  Everything timed runs through the C-ABI of libdfft_mi355x (HIP kernels + RCCL); the oracle and
+the reference's heFFTe stock CPU backend are used only for the error check and the cpu_baseline leg on rank 0.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_COPY_CEILING_GBS = 6290.0
+
+
+def parse_size(s: str):
+    p = [int(v) for v in s.lower().split("x")]
+    if len(p) == 1:
+        p = p * 3
+    assert len(p) == 3
+    return tuple(p)
+
+
+def cpu_baseline(sample_n: int = 256):
+    """CPU leg (rank 0, N=1 only): the reference's bundled heFFTe 2.1.0 stock backend (oracle/_ref/speed3d_c2c, built from
+    /root/reference sources by oracle/Makefile) on a bounded sample; falls back to timing the C restatement (a port)."""
+    cores = os.cpu_count() or 1
+    ranks = 1
+    while ranks * 2 <= min(cores, 64):
+        ranks *= 2
+    exe = ROOT / "oracle" / "_ref" / "speed3d_c2c"
+    mpirun = Path("/opt/conda/bin/mpirun")
+    flops = 5.0 * sample_n ** 3 * math.log2(sample_n ** 3) * 1e-9
+    if exe.exists() and mpirun.exists():
+        try:
+            env = dict(os.environ)
+            env["LD_LIBRARY_PATH"] = str(exe.parent / "mpilib") + ":" + env.get("LD_LIBRARY_PATH", "")
+            r = subprocess.run([str(mpirun), "-np", str(ranks), str(exe), "stock", "double", str(sample_n), str(sample_n),
+                                str(sample_n), "-slabs", "-p2p_pl"], capture_output=True, text=True, timeout=240, env=env,
+                               cwd="/tmp")
+            perf = [l for l in r.stdout.splitlines() if l.strip().startswith("Performance:")]
+            tim = [l for l in r.stdout.splitlines() if l.strip().startswith("Time per run:")]
+            if r.returncode == 0 and perf:
+                return {"value": float(perf[0].split()[1]), "unit": "GFlops/s", "cores": ranks, "kind": "reference",
+                        "sample": f"heFFTe 2.1.0 stock backend (bundled with the reference), {sample_n}^3 fp64 C2C, "
+                                  f"mpirun -np {ranks} -slabs -p2p_pl, {tim[0].strip() if tim else ''} "
+                                  f"(host has {cores} hardware threads)"}
+        except Exception:
+            pass
+    from oracle import slab_oracle as so
+    n = 128
+    x = so.random_input((n, n, n), seed=3)
+    t = time.perf_counter()
+    so.c_slab_fft3d(x, (n, n, n), 1, +1)
+    dt = time.perf_counter() - t
+    return {"value": 5.0 * n ** 3 * math.log2(n ** 3) * 1e-9 / dt, "unit": "GFlops/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/slab_oracle.c (scalar C restatement), {n}^3 fp64 forward, 1 thread, {dt:.3f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=parse_size, default=(512, 512, 512))
+    ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="reference stage structure (separate pack / transpose)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from distributedfft_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    P = world
+    comm = None
+    if P > 1:
+        # control plane on gloo (barriers, max-reduce, id broadcast); the data plane (t2) is RCCL inside the library
+        dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(api.Comm.rccl_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(uid, src=0)
+        comm = api.Comm.rccl(bytes(uid.tolist()), P, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if P > 1:
+            dist.barrier()
+
+    n0, n1, n2 = args.size
+    N = n0 * n1 * n2
+    cdt = torch.complex128 if args.precision == "fp64" else torch.complex64
+    rdt = torch.float64 if args.precision == "fp64" else torch.float32
+    S = 16 if args.precision == "fp64" else 8
+    tot, inr, counts = api.fft_mpi_init(args.size, 1, mpi_size=P, mpi_rank=rank)
+    if tot != P:
+        raise SystemExit(f"{n0} planes cannot be split over {P} devices the way the reference does (got {tot})")
+    count = counts[0]
+    max_count = api.get_max_data_count(n0, n1, n2, P, rank == P - 1)
+
+    # synthetic input of this rank's X-slab, resident in HBM before anything is timed
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    a = torch.zeros(max_count, dtype=cdt, device=dev)
+    re = torch.rand(count, generator=gen, device=dev, dtype=rdt) * 2 - 1
+    im = torch.rand(count, generator=gen, device=dev, dtype=rdt) * 2 - 1
+    a[:count] = torch.complex(re, im)
+    del re, im
+    b = torch.zeros(max_count, dtype=cdt, device=dev)
+    flags = api.PLAN_INPUT_FROM_IN | (api.PLAN_UNFUSED if args.unfused else 0)
+    plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
+
+    for _ in range(args.warmup):
+        plan.execute(api.EXEC_ASYNC)
+    plan.sync()
+
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        plan.execute(api.EXEC_ASYNC)
+    plan.sync()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if P > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sec_per_step = elapsed / args.steps
+    gflops = 5.0 * N * math.log2(N) * 1e-9 / sec_per_step
+
+    # ---- per-stage / per-kernel breakdown from HIP events on the plan's stream (separate, untimed executes) ----
+    stage, kern = [], []
+    for _ in range(10):
+        barrier()
+        plan.execute(api.EXEC_ASYNC)
+        stage.append(plan.stage_times())
+        if not args.unfused:
+            kern.append(plan.kernel_times())
+    stage = np.median(np.array(stage), axis=0)
+    kern = np.median(np.array(kern), axis=0) if kern else None
+    if P > 1:
+        t = torch.tensor(np.concatenate([stage, kern if kern is not None else np.zeros(3)]), dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        stage = t[:4].numpy()
+        kern = t[4:].numpy() if kern is not None else None
+
+    # ---- error: the driver's round-trip metric (fftSpeed3d_c2c.cpp:84-91) on the device, plus an oracle spot check ----
+    fwd_out = b.clone()
+    c = torch.zeros(max_count, dtype=cdt, device=dev)
+    planb = api.Plan(n0, n1, n2, fwd_out, c, comm, rank, P, api.BACKWARD, api.PLAN_DEFAULT)
+    barrier()
+    planb.execute(api.EXEC_ASYNC)
+    planb.sync()
+    rt_err = float((a[:count] - c[:count] / N).abs().max().item())
+    if P > 1:
+        t = torch.tensor([rt_err], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rt_err = float(t.item())
+    planb.destroy()
+    del c, fwd_out
+
+    result = None
+    if rank == 0:
+        local_bytes = 2.0 * S * (N / P)  # each compute stage reads + writes its N/P elements once
+        names = ["fft_rows Z", "fft_cols Y(+pack)", "fft_cols X(+transpose)"]
+        roof = None
+        if kern is not None:
+            k = int(np.argmax(kern))
+            ach = local_bytes / kern[k] / 1e9
+            roof = {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
+                    "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
+                    "avg_launch_ms": round(float(kern[k]) * 1e3, 4),
+                    "all_kernels": {n: {"ms": round(float(t_) * 1e3, 4), "GB/s": round(local_bytes / t_ / 1e9, 1)}
+                                    for n, t_ in zip(names, kern)},
+                    "local_pipeline": {"bytes": 2 * local_bytes, "GB/s": round(2 * local_bytes / float(stage[0] + stage[1] + stage[3]) / 1e9, 1)}}
+            tfile = ROOT / "profiles" / "hbm_traffic.json"
+            if tfile.exists():
+                try:
+                    tr = json.loads(tfile.read_text())
+                    key = f"{n0}x{n1}x{n2}_{args.precision}_P{P}"
+                    if key in tr and names[k] in tr[key]:
+                        roof["traffic"] = tr[key][names[k]]["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = tr[key].get("source", "profiles/")
+                except Exception:
+                    pass
+        total_stage = float(sum(stage))
+        result = {
+            "metric": "GFlops/s forward 3D C2C (5 N log2 N), 512^3 fp64" if args.size == (512, 512, 512) and args.precision == "fp64"
+                      else f"GFlops/s forward 3D C2C (5 N log2 N), {n0}x{n1}x{n2} {args.precision}",
+            "value": round(gflops, 2), "unit": "GFlops/s", "n_gpus": P, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
+            "config": {"workload": f"{n0}x{n1}x{n2} C2C {args.precision} forward, slab decomposition over {P} GPU(s), "
+                                   f"{'fused' if not args.unfused else 'unfused'} pipeline, input resident in HBM",
+                       "parallelism": f"slab{P}", "exchange": "none (P=1)" if P == 1 else "RCCL grouped send/recv over xGMI"},
+            "max_error": rt_err / 1e7, "roundtrip_abs_error": rt_err,
+            "stages_ms": {"t0": round(float(stage[0]) * 1e3, 4), "t1": round(float(stage[1]) * 1e3, 4),
+                          "t2": round(float(stage[2]) * 1e3, 4), "t3": round(float(stage[3]) * 1e3, 4)},
+            "t2_fraction": round(float(stage[2]) / total_stage, 4) if total_stage > 0 else None,
+            "roofline": roof,
+            "reference_published": {"value": 644.112, "unit": "GFlops/s", "config": "512^3 fp64, 4 ranks, unnamed AMD GPUs "
+                                    "(README.md:54 of the reference); comparable only at n_gpus=4"},
+        }
+        if P == 4 and args.size == (512, 512, 512) and args.precision == "fp64":
+            result["vs_baseline"] = round(gflops / 644.112, 3)
+        if P > 1 and stage[2] > 0:
+            pair = S * N / (P * P)
+            result["xgmi"] = {"pair_chunk_bytes": pair, "achieved_GB/s_per_link": round(pair / float(stage[2]) / 1e9, 1),
+                              "peak_GB/s_per_link": 153.0}
+        if P == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+    plan.destroy()
+    if comm is not None:
+        comm.destroy()
+    if P > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,7 +10,8 @@ import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "lib" / "libdfft_mi355x.so"
+LIB_PATH_SYSTEM = _PKG / "lib" / "libdfft_mi355x.so"   # linked against /opt/rocm: for C++ hosts (distFFTOpt)
+LIB_PATH = _PKG / "lib" / "libdfft_mi355x_pt.so"       # same objects linked against PyTorch's bundled HIP/RCCL runtime
 DRIVER_PATH = _PKG / "lib" / "distFFTOpt"
 
 # constants mirrored from include/dfft.h
@@ -49,6 +50,7 @@ SIGNATURES = {
     "dfft_execute": (C.c_int, [_VP, C.c_uint]),
     "dfft_plan_sync": (C.c_int, [_VP]),
     "dfft_stage_times": (C.c_int, [_VP, C.POINTER(C.c_double)]),
+    "dfft_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "dfft_plan_destroy": (C.c_int, [_VP]),
     "dfft_fft1d_rows": (C.c_int, [_VP, _VP, _LL, _LL, C.c_int, C.c_int, _VP]),
     "dfft_fft1d_cols": (C.c_int, [_VP, _VP, _LL, _LL, _LL, C.c_int, C.c_int, _VP]),
@@ -76,6 +78,11 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     path = Path(os.environ.get("DFFT_LIB", str(LIB_PATH)))
+    try:  # make sure the HIP runtime this variant binds to is torch's, already resident in the process
+        import torch  # noqa: F401
+    except ImportError:
+        if "DFFT_LIB" not in os.environ:
+            path = LIB_PATH_SYSTEM
     if not path.exists():
         raise ImportError(
             f"{path} not found: build the HIP extension first (python -m distributedfft_amd.build, or "

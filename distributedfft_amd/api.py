@@ -131,6 +131,7 @@ class Plan:
             raise ValueError(f"in/out must hold getMaxDataCount = {self.max_count} elements")
         self._in, self._out, self._comm = inp, out, comm  # keep alive
         self.handle = C.c_void_p()
+        torch.cuda.synchronize(inp.device)  # plan creation copies `in` with a blocking hipMemcpy on the null stream
         with torch.cuda.device(inp.device):
             L.check(lib.dfft_plan_create(C.byref(self.handle), n0, n1, n2, self.dtype, direction, inp.data_ptr(),
                                          out.data_ptr() if out is not None else None,
@@ -183,6 +184,12 @@ class Plan:
     def stage_times(self) -> List[float]:
         t = (C.c_double * 4)()
         L.check(L.load().dfft_stage_times(self.handle, t), "dfft_stage_times")
+        return list(t)
+
+    def kernel_times(self) -> List[float]:
+        """Seconds spent in the Z-row, Y-column and X-column FFT kernels of the last ASYNC execute (HIP events)."""
+        t = (C.c_double * 3)()
+        L.check(L.load().dfft_kernel_times(self.handle, t), "dfft_kernel_times")
         return list(t)
 
     def destroy(self) -> None:

@@ -26,7 +26,20 @@ NUM_INST_GROUPS = 7  # keep in sync with csrc/dfft_plans.h
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + str(INCLUDE), "-I" + str(CSRC),
           "-Wno-unused-result"]
 
-LIB_NAME = "libdfft_mi355x.so"
+LIB_NAME = "libdfft_mi355x.so"       # links /opt/rocm (standalone C++ applications, distFFTOpt)
+LIB_NAME_PT = "libdfft_mi355x_pt.so"  # links the runtime bundled with PyTorch (Python hosts)
+
+
+def _torch_lib_dir():
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        d = Path(spec.origin).parent / "lib"
+        return d if (d / "libamdhip64.so").exists() and (d / "librccl.so").exists() else None
+    except Exception:
+        return None
 
 
 def _newer(target: Path, deps) -> bool:
@@ -76,6 +89,16 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     if force or any(rebuilt) or _newer(lib, objs):
         _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", str(lib)] + objs +
              ["-L" + str(ROCM / "lib"), "-lrccl", "-Wl,-rpath," + str(ROCM / "lib")])
+
+    # Same objects linked against the HIP/RCCL runtime that PyTorch bundles (torch/lib): a Python process that has
+    # imported torch must not get a second HIP runtime from /opt/rocm next to torch's own (two runtimes in one
+    # process = sporadic hipErrorUnknown and heap corruption at exit).  ctypes loads this variant (_lib.py).
+    tl = _torch_lib_dir()
+    if tl is not None:
+        lib_pt = LIBDIR / LIB_NAME_PT
+        if force or any(rebuilt) or _newer(lib_pt, objs):
+            _run(["g++", "-shared", "-fPIC", "-o", str(lib_pt)] + objs +
+                 ["-L" + str(tl), "-l:libamdhip64.so", "-l:librccl.so", "-lpthread", "-Wl,-rpath," + str(tl)])
 
     # driver: our clone, built against the MPI shim (no MPI installation needed)
     drv = LIBDIR / "distFFTOpt"

@@ -20,6 +20,9 @@
 //   u     = DFT_R(u)
 //   dst   = (jq / Ns) * Ns * R + (jq mod Ns) + r*Ns        (scatter through LDS, skipped for the last stage)
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
 #include "dfft_butterfly.h"
 #include "dfft_kernels.h"
 
@@ -91,7 +94,13 @@ template <class V, class P, int S, int DIR> __device__ __forceinline__ void load
     }
 }
 
-template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, bool TWLDS>
+// TWMODE: where a stage finds its twiddles.
+//   TW_REG    per-thread set preloaded into VGPRs (small plans: <= 16 complex per thread)
+//   TW_LDS    direction-adjusted N-entry table staged in LDS once per block
+//   TW_GLOBAL N-entry table read through L1/L2 (only when the LDS is needed for the exchange tile, e.g. N = 2048)
+enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
+
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE>
 __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, int c) {
     using SI = StageInfo<P, S>;
     constexpr int R = SI::R, B = SI::B, NS = SI::NS, T = P::T, E = P::E;
@@ -101,11 +110,18 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[q + r * B];
         if constexpr (S > 0) {
-            if constexpr (TWLDS) {
-                // twr = direction-adjusted N-entry table staged in LDS (plans whose twiddle set would not fit VGPRs)
+            if constexpr (TWMODE == TW_LDS) {
                 const int m = ((j + q * T) % NS) * (P::N / (NS * R));
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[r * m]);
+            } else if constexpr (TWMODE == TW_GLOBAL) {
+                const int m = ((j + q * T) % NS) * (P::N / (NS * R));
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
+                    V w = twr[r * m];
+                    if (DIR < 0) w.y = -w.y;
+                    u[r] = cmul(u[r], w);
+                }
             } else {
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[SI::TWOFF + q * (R - 1) + (r - 1)]);
@@ -127,7 +143,7 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
         group_sync<WAVE_LOCAL>();
 #pragma unroll
         for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWLDS>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE>(v, twr, lds, j, c);
     }
 }
 
@@ -135,11 +151,13 @@ template <class V, class P, int CB, int G> struct KernelGeom {
     static constexpr int GT = CB * P::T;  // threads cooperating on one tile
     static constexpr int THREADS = GT * G;
     static constexpr bool WAVE_LOCAL = (GT <= 64) && (64 % GT == 0);
-    static constexpr bool PAD = (CB * (int)sizeof(V) < 128) && (P::N >= 16);
+    static constexpr bool PAD = (CB == 1) && (P::N >= 16);
     static constexpr int LDS_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
-    // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex), otherwise in an LDS copy of the table.
-    static constexpr bool TWLDS = TwTotal<P>::value > 16;
-    static constexpr int TW_ELEMS = TWLDS ? P::N : 0;
+    // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex); otherwise in an LDS copy of the
+    // table, unless that would push the block past 128 KiB of LDS (then they are read through L1/L2).
+    static constexpr int TWMODE = TwTotal<P>::value <= 16 ? TW_REG
+                                  : (((size_t)LDS_ELEMS * G + P::N) * sizeof(V) <= 128 * 1024 ? TW_LDS : TW_GLOBAL);
+    static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;
     static constexpr size_t LDS_BYTES = ((size_t)LDS_ELEMS * G + TW_ELEMS) * sizeof(V);
 };
 
@@ -159,10 +177,12 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
     const int c = tid % CB;
     const int j = tid / CB;
 
-    constexpr int TWN = KG::TWLDS ? 0 : TwTotal<P>::value;
+    constexpr int TWN = KG::TWMODE == TW_REG ? TwTotal<P>::value : 0;
     V twreg[TWN > 0 ? TWN : 1];
     const V* twr = twreg;
-    if constexpr (KG::TWLDS) {
+    if constexpr (KG::TWMODE == TW_GLOBAL) {
+        twr = tw;
+    } else if constexpr (KG::TWMODE == TW_LDS) {
         for (int i = threadIdx.x; i < P::N; i += KG::THREADS) {
             V w = tw[i];
             if (DIR < 0) w.y = -w.y;
@@ -212,7 +232,7 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
             for (int k = 0; k < E; ++k) v[k] = V{0, 0};
         }
 
-        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWLDS>(v, twr, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE>(v, twr, lds, j, c);
 
         if (valid) {
 #pragma unroll
@@ -242,31 +262,52 @@ inline const DeviceInfo& device_info() {
     return di;
 }
 
+inline hipError_t launch_debug(hipError_t e, const char* what, int lds, int threads) {
+    if (getenv("DFFT_DEBUG"))
+        fprintf(stderr, "[dfft] %s failed: %d (%s), lds=%d threads=%d\n", what, (int)e, hipGetErrorString(e), lds, threads);
+    return e;
+}
+
 template <class V, class P, int CB, int G, int DIR, bool GENERAL>
 hipError_t launch_variant(const FftLaunch& L, hipStream_t stream) {
     using KG = KernelGeom<V, P, CB, G>;
     auto kern = fft_tiles_kernel<V, P, CB, G, DIR, GENERAL>;
     // blocks/CU is a property of the kernel; computed once per process (same for all gfx950 devices).
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
+    // Per-device one-time set-up (function attributes are per device context): LDS opt-in and resident blocks per CU.
+    static int blocks_per_cu[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (blocks_per_cu[dev] == 0) {
         if (KG::LDS_BYTES > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)KG::LDS_BYTES);
-            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)KG::LDS_BYTES);
+            if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)KG::LDS_BYTES, KG::THREADS);
         }
         int occ = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, KG::THREADS, KG::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = occ > 0 ? occ : 1;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, KG::THREADS, KG::LDS_BYTES);
+        if (e != hipSuccess) {
+            // advisory only (the grid-stride loop is correct for any grid): fall back to the LDS / wave-slot bound
+            launch_debug(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor", (int)KG::LDS_BYTES, KG::THREADS);
+            (void)hipGetLastError();
+            const int waves = (KG::THREADS + 63) / 64;
+            occ = 32 / waves;
+            if (KG::LDS_BYTES > 0 && (int)(160 * 1024 / KG::LDS_BYTES) < occ) occ = (int)(160 * 1024 / KG::LDS_BYTES);
+        }
+        blocks_per_cu[dev] = occ > 0 ? occ : 1;
     }
     const long long nblocks_needed = (L.ntiles + G - 1) / G;
-    long long grid = (long long)device_info().cus * blocks_per_cu;
+    long long grid = (long long)device_info().cus * blocks_per_cu[dev];
     if (grid > nblocks_needed) grid = nblocks_needed;
     if (grid < 1) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const V*)L.in, (V*)L.out,
                        (const V*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles, (unsigned)L.tiles_per_a,
                        L.ncols);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)KG::LDS_BYTES, KG::THREADS);
+    return hipSuccess;
 }
 
 template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };

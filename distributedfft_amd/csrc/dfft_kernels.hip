@@ -75,6 +75,7 @@ hipError_t launch_pack(int dtype, int dir, const void* in, void* out, int xl, in
                        hipStream_t stream) {
     const long long nrows = (long long)xl * n1;
     if (nrows <= 0) return hipSuccess;
+    (void)hipGetLastError();
     long long grid = (nrows + 3) / 4;
     if (grid > 256 * 8) grid = 256 * 8;
     if (dtype == F64) {
@@ -118,6 +119,7 @@ hipError_t launch_transpose(int dtype, const void* in, void* out, long long rows
     const long long tiles_r = (rows + 63) / 64, tiles_c = (cols + 63) / 64;
     const long long grid = tiles_r * tiles_c;
     if (grid >= (1ll << 31)) return hipErrorInvalidValue;
+    (void)hipGetLastError();
     if (dtype == F64) {
         constexpr int lds = 64 * 65 * (int)sizeof(double2);  // 66,560 B > the 64 KiB default cap
         static bool attr_set = false;
@@ -148,6 +150,7 @@ template <class V, class R> __global__ void __launch_bounds__(256) scale_kernel(
 
 hipError_t launch_scale(int dtype, void* data, long long count, double s, hipStream_t stream) {
     if (count <= 0) return hipSuccess;
+    (void)hipGetLastError();
     long long grid = (count + 255) / 256;
     if (grid > 256 * 8) grid = 256 * 8;
     if (dtype == F64) hipLaunchKernelGGL((scale_kernel<double2, double>), dim3((unsigned)grid), dim3(256), 0, stream, (double2*)data, count, s);

@@ -142,7 +142,7 @@ struct dfft_plan_s {
     dfft_comm_t comm;
     int         device;
     hipStream_t stream;
-    hipEvent_t  ev[5];
+    hipEvent_t  ev[6];  // [0..4] stage boundaries, [5] between the two FFT kernels of the YZ stage
     double      host_t[4];
     bool        host_timed;
     ExchangeDesc xd;
@@ -309,6 +309,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // ---- t0: 2D YZ FFT of every owned plane ----
     const void* zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, p->xs * n1, p->dtype, p->direction, p->stream));
+    if (!sync) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
     if (fused && p->P > 1) {
         DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true));  // Y FFT + pack in one pass
         DFFT_TRY(clk.end_stage());
@@ -382,6 +383,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
         DFFT_TRY(clk.end_stage());
         DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false));
     }
+    if (!sync) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
     DFFT_TRY(fft_rows(ybuf, ybuf, (int)n2, p->xs * n1, p->dtype, p->direction, p->stream));
     DFFT_TRY(clk.end_stage());
     return DFFT_OK;
@@ -633,6 +635,27 @@ int dfft_stage_times(dfft_plan_t plan, double t[4]) {
         DFFT_HIP_TRY(hipEventElapsedTime(&ms, plan->ev[i], plan->ev[i + 1]));
         t[i] = ms * 1e-3;
     }
+    return DFFT_OK;
+}
+
+int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
+    if (!plan || !t) return fail(DFFT_EINVAL, "dfft_kernel_times: bad arguments");
+    if (plan->host_timed) return fail(DFFT_EINVAL, "dfft_kernel_times: needs an execute without DFFT_EXEC_SYNC_STAGES");
+    if (plan->flags & DFFT_PLAN_UNFUSED) return fail(DFFT_EINVAL, "dfft_kernel_times: fused plans only");
+    DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    float z = 0, y = 0, x = 0;
+    if (plan->direction == DFFT_FORWARD) {
+        DFFT_HIP_TRY(hipEventElapsedTime(&z, plan->ev[0], plan->ev[5]));
+        DFFT_HIP_TRY(hipEventElapsedTime(&y, plan->ev[5], plan->ev[1]));
+        DFFT_HIP_TRY(hipEventElapsedTime(&x, plan->ev[3], plan->ev[4]));
+    } else {
+        DFFT_HIP_TRY(hipEventElapsedTime(&x, plan->ev[0], plan->ev[1]));
+        DFFT_HIP_TRY(hipEventElapsedTime(&y, plan->ev[3], plan->ev[5]));
+        DFFT_HIP_TRY(hipEventElapsedTime(&z, plan->ev[5], plan->ev[4]));
+    }
+    t[0] = z * 1e-3;
+    t[1] = y * 1e-3;
+    t[2] = x * 1e-3;
     return DFFT_OK;
 }
 

@@ -119,6 +119,9 @@ int dfft_plan_sync(dfft_plan_t plan);
 /* Stage times of the last forward/backward execute in seconds: t[0..3] = t0..t3 (backward: X, exchange, unpack, YZ),
  * from HIP events on the plan's stream (ASYNC) or host clocks (SYNC_STAGES).  Syncs the stream. */
 int dfft_stage_times(dfft_plan_t plan, double t[4]);
+/* Durations in seconds of the three FFT kernels of the last ASYNC execute of a fused plan: t[0] = Z rows, t[1] = Y columns
+ * (+pack), t[2] = X columns (+transpose); HIP events on the plan's stream.  Used for the roofline figures. */
+int dfft_kernel_times(dfft_plan_t plan, double t[3]);
 /* fft_mpi_destroy_plan (fft_mpi_3d_api.cpp:143-179). */
 int dfft_plan_destroy(dfft_plan_t plan);
 

@@ -42,6 +42,9 @@ static int make_plan(int n, int* radix) {
     while (m % 3 == 0) { radix[cnt++] = 3; m /= 3; }
     while (m % 5 == 0) { radix[cnt++] = 5; m /= 5; }
     while (m % 7 == 0) { radix[cnt++] = 7; m /= 7; }
+    /* oracle only: any other small prime factor as a by-definition DFT stage (lets the N = 11 golden vector through) */
+    for (int p = 11; p <= 61 && m > 1; p += 2)
+        while (m % p == 0) { radix[cnt++] = p; m /= p; }
     if (m != 1) return 0;
     return cnt;
 }
@@ -60,7 +63,7 @@ static void stockham(const cplx* in, cplx* out, cplx* tmp, int n, int dir, const
         const int nb = n / r; /* butterflies */
         cplx* dst = bufs[st & 1];
         for (int j = 0; j < nb; ++j) {
-            cplx u[8], v[8];
+            cplx u[64], v[64];
             const int jm = j % S;
             for (int k = 0; k < r; ++k) {
                 cplx x = src[j + k * nb];

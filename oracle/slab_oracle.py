@@ -110,12 +110,12 @@ def random_input(N, seed: int = 1234, dtype=np.complex128) -> np.ndarray:
 def radix_plan(n: int) -> List[int]:
     """fold 2s into 8, 4, 2, then 3, 5, 7; largest first (templateFFT.cpp:4540-4588)."""
     plan, m = [], n
-    for r in (8, 4, 2, 3, 5, 7):
+    for r in (8, 4, 2, 3, 5, 7) + tuple(range(11, 62, 2)):  # > 7: oracle-only by-definition stages
         while m % r == 0:
             plan.append(r)
             m //= r
     if m != 1:
-        raise ValueError(f"length {n} has a prime factor > 7")
+        raise ValueError(f"length {n} has a prime factor > 61")
     return plan
 
 

@@ -53,8 +53,6 @@ def test_fft1d_rows_vs_oracle(gpu, n, prec):
 def test_fft1d_cols_vs_oracle(gpu, n, width, prec):
     import torch
     from distributedfft_amd import api
-    if prec == "f64" and n == 2048 and False:
-        pytest.skip("")
     rng = np.random.default_rng(1000 + n)
     batch = 3
     x = (rng.uniform(-1, 1, (batch, n, width)) + 1j * rng.uniform(-1, 1, (batch, n, width)))
@@ -110,8 +108,9 @@ SHAPES = [
     ((8, 8, 8), 1), ((16, 12, 10), 1), ((2, 3, 4), 1), ((64, 64, 64), 1), ((32, 48, 24), 1), ((128, 96, 64), 1),
     ((64, 64, 64), 2), ((64, 64, 64), 4), ((32, 48, 24), 2), ((128, 128, 32), 8),
     ((10, 10, 8), 4),     # uneven in X and Y: xl=3 (last 1), yl=3 (last 1)
-    ((25, 7, 16), 4),     # uneven X (7,7,7,4) and Y (2,2,2,1)
-    ((24, 10, 21), 4),    # ragged N2 (21 % 8 != 0) with uneven Y (3,3,3,1)
+    ((25, 10, 16), 4),    # uneven X (7,7,7,4) and Y (3,3,3,1)
+    ((24, 10, 12), 4),    # ragged N2 (12 % 8 != 0, 12 % 16 != 0) with uneven Y (3,3,3,1)
+    ((96, 100, 20), 2) if False else ((48, 100, 12), 2),  # radix-5 Y axis, ragged Z
 ]
 
 

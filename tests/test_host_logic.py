@@ -1,0 +1,154 @@
+"""CPU tests of the host side of the C-ABI: slab bookkeeping against the oracle's restatement of the reference formulas,
+the exported symbol set, the CLI surface of the driver, and loud failure without a GPU.  No compute calls."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import slab_oracle as so
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _ll(v):
+    return (C.c_longlong * len(v))(*v)
+
+
+@pytest.mark.parametrize("N,ini,size", [((512, 512, 512), 1, 4), ((512, 512, 512), 1, 8), ((100, 64, 64), 1, 8),
+                                        ((100, 64, 64), 2, 4), ((10, 8, 8), 1, 4), ((1024, 768, 512), 1, 8),
+                                        ((7, 8, 8), 4, 2), ((5, 4, 4), 1, 3)])
+def test_proper_device_count_matches_reference_formula(native_lib, N, ini, size):
+    """getProperDeviceNum, fft_mpi_3d_api.cpp:232-272."""
+    for rank in range(size):
+        tot, inr = C.c_int(), C.c_int()
+        rc = native_lib.dfft_proper_device_count(_ll(N), ini, size, rank, -1, C.byref(tot), C.byref(inr))
+        want = so.proper_device_num(N, ini, size, rank)
+        if want[1] == 0:
+            assert rc != 0
+            continue
+        assert rc == 0 and (tot.value, inr.value) == want
+    # worked example: N0 = 100 over 8 devices -> 13 planes each, 8 devices, last holds 9 (fft_mpi_3d_api.cpp:244-259)
+    if N[0] == 100 and ini * size == 8:
+        assert tot.value == 8
+        assert native_lib.dfft_local_count(_ll(N), 8, 7) == 9 * N[1] * N[2]
+        assert native_lib.dfft_local_count(_ll(N), 8, 0) == 13 * N[1] * N[2]
+
+
+def test_clamp_to_visible_devices(native_lib):
+    tot, inr = C.c_int(), C.c_int()
+    assert native_lib.dfft_proper_device_count(_ll((64, 64, 64)), 4, 1, 0, 1, C.byref(tot), C.byref(inr)) == 0
+    assert (tot.value, inr.value) == (1, 1)  # fft_mpi_3d_api.cpp:236-239
+    assert native_lib.dfft_proper_device_count(_ll((64, 64, 64)), 4, 1, 0, 0, C.byref(tot), C.byref(inr)) != 0
+
+
+@pytest.mark.parametrize("N,P", [((512, 512, 512), 4), ((1024, 768, 512), 8), ((2048, 2048, 1024), 8), ((10, 10, 8), 4),
+                                 ((25, 10, 16), 4), ((64, 64, 64), 1), ((100, 64, 32), 8)])
+def test_counts_offsets_and_max_count(native_lib, N, P):
+    """getMaxDataCount :289-316, tInfo :84-133, receive offsets :618-625; plus conservation properties."""
+    n0, n1, n2 = N
+    for g in range(P):
+        last = g == P - 1
+        assert native_lib.dfft_max_count(n0, n1, n2, P, int(last)) == so.max_data_count(n0, n1, n2, P, last)
+        for direction in (1, -1):
+            arrs = [(C.c_longlong * P)() for _ in range(4)]
+            assert native_lib.dfft_exchange_layout(n0, n1, n2, P, g, direction, *arrs) == 0
+            want = so.exchange_layout(n0, n1, n2, P, g, direction)
+            assert [list(a) for a in arrs] == [list(w) for w in want]
+            sc, so_, rc, ro = [list(a) for a in arrs]
+            mc = so.max_data_count(n0, n1, n2, P, last)
+            assert all(o + c <= mc for o, c in zip(so_, sc)) and all(o + c <= mc for o, c in zip(ro, rc))
+            # chunks tile the buffers without overlap
+            for cnt, off in ((sc, so_), (rc, ro)):
+                iv = sorted((o, o + c) for o, c in zip(off, cnt) if c)
+                assert all(a[1] <= b[0] for a, b in zip(iv, iv[1:]))
+        v = [C.c_longlong() for _ in range(4)]
+        assert native_lib.dfft_local_size(n0, n1, n2, P, g, *[C.byref(x) for x in v]) == 0
+        assert [x.value for x in v] == [so.slab_size(n0, P, g), so.slab_start(n0, P, g), so.slab_size(n1, P, g),
+                                        so.slab_start(n1, P, g)]
+    # what g sends to d is what d expects from g
+    for direction in (1, -1):
+        lay = [so.exchange_layout(n0, n1, n2, P, g, direction) for g in range(P)]
+        for g in range(P):
+            for d in range(P):
+                assert lay[g][0][d] == lay[d][2][g]
+    total = sum(native_lib.dfft_local_count(_ll(N), P, g) for g in range(P))
+    assert total == n0 * n1 * n2
+
+
+def test_published_config_shapes(native_lib):
+    """per-GPU slab and pair-chunk sizes of the BASELINE configs."""
+    assert native_lib.dfft_max_count(512, 512, 512, 4, 0) == 33554432            # 512 MiB of fp64 complex
+    arrs = [(C.c_longlong * 4)() for _ in range(4)]
+    native_lib.dfft_exchange_layout(512, 512, 512, 4, 1, 1, *arrs)
+    assert list(arrs[0]) == [8388608] * 4                                          # 128 MiB pair chunks
+    arrs = [(C.c_longlong * 8)() for _ in range(4)]
+    native_lib.dfft_exchange_layout(1024, 768, 512, 8, 0, 1, *arrs)
+    assert list(arrs[0]) == [128 * 96 * 512] * 8                                    # 96 MiB
+    native_lib.dfft_exchange_layout(2048, 2048, 1024, 8, 3, 1, *arrs)
+    assert list(arrs[0]) == [256 * 256 * 1024] * 8                                  # 512 MiB in fp32
+
+
+def test_bad_arguments_return_codes(native_lib):
+    assert native_lib.dfft_max_count(8, 8, 8, 0, 0) == -1
+    assert native_lib.dfft_exchange_layout(8, 8, 8, 4, 4, 1, None, None, None, None) != 0
+    assert native_lib.dfft_exchange_layout(8, 8, 8, 4, 0, 0, None, None, None, None) != 0
+    # last Y slab empty: N1 = 9 over 4 devices -> 3,3,3,0 (the reference cannot run this either)
+    assert native_lib.dfft_exchange_layout(16, 9, 8, 4, 0, 1, None, None, None, None) != 0
+    assert b"last slab" in native_lib.dfft_last_error()
+    for n, ok in [(512, 1), (768, 1), (1024, 1), (2048, 1), (256, 1), (7, 0), (11, 0), (4096, 0), (0, 0), (-4, 0)]:
+        assert native_lib.dfft_length_supported(n) == ok
+
+
+def test_header_and_library_export_the_same_symbols(native_lib):
+    """Every function include/dfft.h declares is exported by both builds of the library and bound in _lib.SIGNATURES."""
+    from distributedfft_amd import _lib
+    hdr = (ROOT / "include" / "dfft.h").read_text()
+    declared = set(re.findall(r"\b(dfft_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_SYSTEM):
+        assert path.exists(), path
+        out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+        exported = set(re.findall(r" T (dfft_[a-z0-9_]+)", out))
+        assert declared <= exported, declared - exported
+    assert native_lib.dfft_version().startswith(b"dfft-mi355x")
+
+
+def test_product_path_fails_loudly_without_gpu(native_lib):
+    """No CPU fallback anywhere: plan creation and the 1D entry points refuse to run when no HIP device is visible."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    assert native_lib.dfft_device_count() == 0
+    buf = np.zeros(8 * 8 * 8, dtype=np.complex128)
+    h = C.c_void_p()
+    rc = native_lib.dfft_plan_create(C.byref(h), 8, 8, 8, 0, 1, buf.ctypes.data, None, None, 0, 1, 0)
+    assert rc == -4 and b"no CPU fallback" in native_lib.dfft_last_error()
+    assert native_lib.dfft_fft1d_rows(buf.ctypes.data, buf.ctypes.data, 8, 64, 0, 1, None) == -4
+    from distributedfft_amd import api
+    with pytest.raises(api.DfftError):
+        api.Plan(8, 8, 8, torch.zeros(512, dtype=torch.complex128), None, None, 0, 1, api.FORWARD)
+
+
+def test_python_mirror_of_init(native_lib):
+    from distributedfft_amd import api
+    tot, inr, counts = api.fft_mpi_init((512, 512, 512), 1, mpi_size=4, mpi_rank=2)
+    assert (tot, inr, counts) == (4, 1, [128 * 512 * 512])
+    assert api.get_max_data_count(512, 512, 512, 4, False) == 33554432
+    lay = api.exchange_layout(512, 512, 512, 4, 2, api.FORWARD)
+    assert lay.soffset == [i * 8388608 for i in range(4)] and lay.roffset == lay.soffset
+    assert api.local_size(1024, 768, 512, 8, 7) == (128, 896, 96, 672)
+
+
+def test_driver_cli_argument_check(native_lib):
+    """fftSpeed3d_c2c.cpp:28-31: exactly four arguments or the format message and a failure exit."""
+    from distributedfft_amd import _lib
+    assert _lib.DRIVER_PATH.exists()
+    r = subprocess.run([str(_lib.DRIVER_PATH), "8", "8"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "The format of arguments should be [NX, NY, NZ, GPU_COUNT]!" in r.stdout
+    assert "ready for attach" in r.stdout
+    sh = (ROOT / "speedTest.sh").read_text()
+    assert "distFFTOpt" in sh and "$2 $3 $4 1" in sh  # speedTest.sh:6 shape: <ranks> X Y Z -> ./distFFTOpt X Y Z 1

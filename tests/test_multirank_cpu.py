@@ -1,0 +1,112 @@
+"""CPU multi-process tests of the N > 1 path (world size 2/3, gloo / TCP):
+  * the exchange layout the library hands to RCCL (dfft_exchange_layout) drives a gloo all_to_all_single over
+    oracle-packed slabs and must reproduce the reference's re-slabbed layout [x][yl][N2] on every rank;
+  * the TCP rendezvous (dfft_boot_*) that replaces MPI's control plane: bcast / barrier / allreduce-max."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+GLOO_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from oracle import slab_oracle as so
+from distributedfft_amd import api
+N = tuple(int(v) for v in os.environ["DFFT_N"].split("x"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+n0, n1, n2 = N
+x = so.random_input(N, seed=77)
+xs0, xsz = so.slab_start(n0, world, rank), so.slab_size(n0, world, rank)
+# local stages t0 + t1 by the oracle (checker), counts/offsets from the product's C-ABI
+send = so.t1_pack(so.t0_fft_yz(x[xs0:xs0 + xsz], +1), world)
+lay = api.exchange_layout(n0, n1, n2, world, rank, api.FORWARD)
+assert lay.soffset == sorted(lay.soffset) and lay.roffset == sorted(lay.roffset)
+sbuf = torch.from_numpy(np.concatenate([send[o:o + c] for o, c in zip(lay.soffset, lay.scount)]).view(np.float64).copy())
+rbuf = torch.empty(2 * sum(lay.rcount), dtype=torch.float64)
+dist.all_to_all_single(rbuf, sbuf, [2 * c for c in lay.rcount], [2 * c for c in lay.scount])
+recv = np.zeros(api.get_max_data_count(n0, n1, n2, world, rank == world - 1), dtype=np.complex128)
+flat = rbuf.numpy().view(np.complex128)
+pos = 0
+for o, c in zip(lay.roffset, lay.rcount):
+    recv[o:o + c] = flat[pos:pos + c]; pos += c
+ys = so.slab_size(n1, world, rank)
+out = so.t3_fft_x(recv, n0, ys, n2, +1)
+ref = so.fftn_reference(x, world)[rank]
+err = float(np.abs(out - ref).max() / np.abs(ref).max())
+# the re-slabbed buffer is exactly [x][ys][N2] of the YZ-transformed array
+yz = np.fft.fft2(x, axes=(1, 2))[:, so.slab_start(n1, world, rank):so.slab_start(n1, world, rank) + ys, :]
+lay_err = float(np.abs(recv[:n0 * ys * n2].reshape(n0, ys, n2) - yz).max())
+t = torch.tensor([err, lay_err]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0: print("RESULT", t[0].item(), t[1].item())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("N,world", [((16, 12, 8), 2), ((10, 10, 4), 2), ((12, 9, 6), 3)])
+def test_gloo_alltoall_with_library_layout(native_lib, N, world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DFFT_ROOT=str(ROOT), DFFT_N="x".join(map(str, N)))
+        procs.append(subprocess.Popen([sys.executable, "-c", GLOO_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < 1e-12 and float(line[2]) < 1e-11
+
+
+BOOT_WORKER = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from distributedfft_amd import _lib
+lib = _lib.load()
+assert lib.dfft_boot_init() == 0, lib.dfft_last_error()
+r, n = lib.dfft_boot_rank(), lib.dfft_boot_size()
+buf = C.create_string_buffer(128)
+if r == 0: buf.raw = bytes(range(128))
+assert lib.dfft_boot_bcast(buf, 128, 0) == 0
+assert buf.raw == bytes(range(128))
+v = (C.c_double * 2)(float(r), -float(r))
+assert lib.dfft_boot_allreduce_max(v, 2) == 0
+assert (v[0], v[1]) == (float(n - 1), 0.0), (v[0], v[1])
+for _ in range(3): assert lib.dfft_boot_barrier() == 0
+assert lib.dfft_boot_finalize() == 0
+print("BOOT_OK", r, n)
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_tcp_rendezvous(native_lib, world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, DFFT_RANK=str(r), DFFT_WORLD_SIZE=str(world), DFFT_MASTER_ADDR="127.0.0.1",
+                   DFFT_MASTER_PORT=str(port), DFFT_ROOT=str(ROOT))
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, "-c", BOOT_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        assert f"BOOT_OK {r} {world}" in o
