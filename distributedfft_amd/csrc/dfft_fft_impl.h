@@ -10,7 +10,8 @@
 //     (stages-1) LDS exchanges (reference: stages+1 LDS round trips, 2*stages barriers);
 //   * a 512-point FFT is exactly one wave64 (64 lanes x 8 points): the row kernel needs no s_barrier at all;
 //   * twiddles e^{-2 pi i r m / (Ns R)} are fetched once per persistent thread into VGPRs and reused for every
-//     tile the block processes (reference: global LUT read per stage per FFT);
+//     tile the block processes (reference: global LUT read per stage per FFT); only the powers 1, 2, 4 are kept, the
+//     others are products (keeps the kernels under 128 VGPRs = 4 waves per SIMD);
 //   * the column kernel keeps CB adjacent columns as the fastest LDS dimension, so every ds_write_b128 /
 //     ds_read_b128 lane group is contiguous (bank-conflict free without padding) and every HBM access is a
 //     full 128-byte line; pack (t1) and the X transpose are folded into the store address map.
@@ -36,23 +37,60 @@ template <int N_, int E_, int... Rs> struct Plan {
     static_assert(N_ % E_ == 0, "E must divide N");
 };
 
-template <class P, int S> struct StageInfo {
-    using Prev = StageInfo<P, S - 1>;
+// Kernel tuning policy (compile time).  The defaults are what the library ships; tools/kbench.hip instantiates others.
+struct TuneDefault {
+    static constexpr bool TWPOW = true;    // keep w^1, w^2, w^4 per butterfly, derive the other powers by products
+    static constexpr bool OSTAGE = false;  // column kernel: stage results through LDS so every wave stores 1 KiB runs
+    static constexpr bool NTL = false;     // non-temporal global loads
+    static constexpr bool NTS = false;     // non-temporal global stores
+    static constexpr int MIN_WAVES = 0;    // amdgpu_waves_per_eu lower bound (0 = let the compiler decide)
+    static constexpr int CB_OVERRIDE = 0;  // columns per tile (0 = cols_per_tile())
+    static constexpr bool PLAIN = false;   // single-block address maps: offsets = base + k*step (no per-point VGPRs)
+};
+
+// Column kernel whose store side is the transposed one ([..][z][kx], kx fastest: the forward X pass).  Measured on
+// MI355X at 512^3 fp64 (tools/kbench, profiles/): direct 128-byte-segment stores 1.20 ms; results staged through LDS so
+// each wave stores 1 KiB runs + two resident blocks per CU (<= 128 VGPRs) + streaming (non-temporal) access 0.92 ms.
+template <int THREADS> struct TuneTransposedStore {
+    static constexpr bool TWPOW = true;
+    static constexpr bool OSTAGE = true;
+    static constexpr bool NTL = true;
+    static constexpr bool NTS = true;
+    static constexpr int MIN_WAVES = THREADS >= 512 ? 4 : 0;
+    static constexpr int CB_OVERRIDE = 0;
+    static constexpr bool PLAIN = false;
+};
+
+// Cache-policy variants for the Infinity-Cache-blocked Z+Y stage (execute_forward/backward in dfft_plan.cpp).
+struct TuneStreamIn : TuneDefault {
+    static constexpr bool NTL = true;
+};
+struct TuneStreamOut : TuneDefault {
+    static constexpr bool NTS = true;
+};
+
+// number of stored twiddle powers per butterfly
+constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 5 ? 3 : (R >= 3 ? 2 : (R >= 2 ? 1 : 0))); }
+
+template <class P, int S, bool TWPOW> struct StageInfo {
+    using Prev = StageInfo<P, S - 1, TWPOW>;
     static constexpr int R = P::R[S];
     static constexpr int NS = Prev::NS * Prev::R;
     static constexpr int B = P::E / R;
+    static constexpr int SLOTS = tw_slots(R, TWPOW);
     static constexpr int TWOFF = Prev::TWOFF + Prev::TWCNT;
-    static constexpr int TWCNT = B * (R - 1);
+    static constexpr int TWCNT = B * SLOTS;
 };
-template <class P> struct StageInfo<P, 0> {
+template <class P, bool TWPOW> struct StageInfo<P, 0, TWPOW> {
     static constexpr int R = P::R[0];
     static constexpr int NS = 1;
     static constexpr int B = P::E / R;
+    static constexpr int SLOTS = 0;
     static constexpr int TWOFF = 0;
     static constexpr int TWCNT = 0;
 };
-template <class P> struct TwTotal {
-    using L = StageInfo<P, P::S - 1>;
+template <class P, bool TWPOW> struct TwTotal {
+    using L = StageInfo<P, P::S - 1, TWPOW>;
     static constexpr int value = L::TWOFF + L::TWCNT;
 };
 
@@ -75,34 +113,37 @@ template <bool WAVE_LOCAL> __device__ __forceinline__ void group_sync() {
     }
 }
 
-template <class V, class P, int S, int DIR> __device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, int j) {
+// stored slot s of a butterfly holds w^{1 << s} when TWPOW, else w^{s+1}
+template <class V, class P, int S, int DIR, bool TWPOW>
+__device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, int j) {
     if constexpr (S < P::S) {
-        using SI = StageInfo<P, S>;
+        using SI = StageInfo<P, S, TWPOW>;
         if constexpr (S > 0) {
 #pragma unroll
             for (int q = 0; q < SI::B; ++q) {
                 const int m = (j + q * P::T) % SI::NS;
 #pragma unroll
-                for (int r = 1; r < SI::R; ++r) {
+                for (int s = 0; s < SI::SLOTS; ++s) {
+                    const int r = TWPOW ? (1 << s) : (s + 1);
                     V w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
                     if (DIR < 0) w.y = -w.y;
-                    twr[SI::TWOFF + q * (SI::R - 1) + (r - 1)] = w;
+                    twr[SI::TWOFF + q * SI::SLOTS + s] = w;
                 }
             }
         }
-        load_twiddles<V, P, S + 1, DIR>(twr, tw, j);
+        load_twiddles<V, P, S + 1, DIR, TWPOW>(twr, tw, j);
     }
 }
 
 // TWMODE: where a stage finds its twiddles.
-//   TW_REG    per-thread set preloaded into VGPRs (small plans: <= 16 complex per thread)
+//   TW_REG    per-thread set preloaded into VGPRs
 //   TW_LDS    direction-adjusted N-entry table staged in LDS once per block
 //   TW_GLOBAL N-entry table read through L1/L2 (only when the LDS is needed for the exchange tile, e.g. N = 2048)
 enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 
-template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE>
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW>
 __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, int c) {
-    using SI = StageInfo<P, S>;
+    using SI = StageInfo<P, S, TWPOW>;
     constexpr int R = SI::R, B = SI::B, NS = SI::NS, T = P::T, E = P::E;
 #pragma unroll
     for (int q = 0; q < B; ++q) {
@@ -122,6 +163,18 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
                     if (DIR < 0) w.y = -w.y;
                     u[r] = cmul(u[r], w);
                 }
+            } else if constexpr (TWPOW) {
+                const V* ws = twr + SI::TWOFF + q * SI::SLOTS;
+                V w[R > 1 ? R : 2];
+                w[1] = ws[0];
+                if constexpr (R >= 3) w[2] = ws[1];
+                if constexpr (R >= 4) w[3] = cmul(w[1], w[2]);
+                if constexpr (R >= 5) w[4] = ws[2];
+                if constexpr (R >= 6) w[5] = cmul(w[4], w[1]);
+                if constexpr (R >= 7) w[6] = cmul(w[4], w[2]);
+                if constexpr (R >= 8) w[7] = cmul(w[4], w[3]);
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
             } else {
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[SI::TWOFF + q * (R - 1) + (r - 1)]);
@@ -132,6 +185,11 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
         for (int r = 0; r < R; ++r) v[q + r * B] = u[r];
     }
     if constexpr (S + 1 < P::S) {
+#ifdef DFFT_DBG_NOEXCH
+        // measurement builds only (tools/kbench): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW>(v, twr, lds, j, c);
+        return;
+#endif
         if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
 #pragma unroll
         for (int q = 0; q < B; ++q) {
@@ -143,31 +201,63 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
         group_sync<WAVE_LOCAL>();
 #pragma unroll
         for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW>(v, twr, lds, j, c);
     }
 }
 
-template <class V, class P, int CB, int G> struct KernelGeom {
+template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     static constexpr int GT = CB * P::T;  // threads cooperating on one tile
     static constexpr int THREADS = GT * G;
     static constexpr bool WAVE_LOCAL = (GT <= 64) && (64 % GT == 0);
     static constexpr bool PAD = (CB == 1) && (P::N >= 16);
-    static constexpr int LDS_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
+    static constexpr bool OSTAGE = Tune::OSTAGE && CB > 1 && P::S > 1;
+    // exchange tile; the staged store needs [CB][N + 1] (one pad element per column keeps the transposed writes on
+    // distinct banks)
+    static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
+    static constexpr int OS_ELEMS = OSTAGE ? (P::N + 1) * CB : 0;
+    static constexpr int LDS_ELEMS = EX_ELEMS > OS_ELEMS ? EX_ELEMS : OS_ELEMS;
+    static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
     // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex); otherwise in an LDS copy of the
     // table, unless that would push the block past 128 KiB of LDS (then they are read through L1/L2).
-    static constexpr int TWMODE = TwTotal<P>::value <= 16 ? TW_REG
+    static constexpr int TWMODE = TWN <= 16 ? TW_REG
                                   : (((size_t)LDS_ELEMS * G + P::N) * sizeof(V) <= 128 * 1024 ? TW_LDS : TW_GLOBAL);
     static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;
     static constexpr size_t LDS_BYTES = ((size_t)LDS_ELEMS * G + TW_ELEMS) * sizeof(V);
 };
 
+template <class V> struct native_vec;
+template <> struct native_vec<double2> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct native_vec<float2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <bool NT, class V> __device__ __forceinline__ V gload(const V* p) {
+    if constexpr (NT) {
+        using NV = typename native_vec<V>::type;
+        const NV t = __builtin_nontemporal_load(reinterpret_cast<const NV*>(p));
+        return V{t.x, t.y};
+    } else {
+        return *p;
+    }
+}
+template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
+    if constexpr (NT) {
+        using NV = typename native_vec<V>::type;
+        NV t;
+        t.x = v.x;
+        t.y = v.y;
+        __builtin_nontemporal_store(t, reinterpret_cast<NV*>(p));
+    } else {
+        *p = v;
+    }
+}
+
 // GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
-template <class V, class P, int CB, int G, int DIR, bool GENERAL>
-__global__ void __launch_bounds__((KernelGeom<V, P, CB, G>::THREADS))
-fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, AxisMap omap,
-                 TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, int ncols) {
-    using KG = KernelGeom<V, P, CB, G>;
-    constexpr int E = P::E, T = P::T, GT = KG::GT;
+template <class V, class P, int CB, int G, int DIR, bool GENERAL, class Tune>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, KernelGeom<V, P, CB, G, Tune>::THREADS),
+                               amdgpu_waves_per_eu(Tune::MIN_WAVES > 0 ? Tune::MIN_WAVES : 1)))
+fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, AxisMap omap, TileMap itile, TileMap otile,
+                 unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first) {
+    using KG = KernelGeom<V, P, CB, G, Tune>;
+    constexpr int E = P::E, T = P::T, GT = KG::GT, N = P::N;
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     V* ldstw = reinterpret_cast<V*>(dfft_smem);
     V* lds = ldstw + KG::TW_ELEMS + (threadIdx.x / GT) * KG::LDS_ELEMS;
@@ -177,13 +267,13 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
     const int c = tid % CB;
     const int j = tid / CB;
 
-    constexpr int TWN = KG::TWMODE == TW_REG ? TwTotal<P>::value : 0;
+    constexpr int TWN = KG::TWMODE == TW_REG ? KG::TWN : 0;
     V twreg[TWN > 0 ? TWN : 1];
     const V* twr = twreg;
     if constexpr (KG::TWMODE == TW_GLOBAL) {
         twr = tw;
     } else if constexpr (KG::TWMODE == TW_LDS) {
-        for (int i = threadIdx.x; i < P::N; i += KG::THREADS) {
+        for (int i = threadIdx.x; i < N; i += KG::THREADS) {
             V w = tw[i];
             if (DIR < 0) w.y = -w.y;
             ldstw[i] = w;
@@ -191,30 +281,42 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         __syncthreads();
         twr = ldstw;
     } else {
-        load_twiddles<V, P, 0, DIR>(twreg, tw, j);
+        load_twiddles<V, P, 0, DIR, Tune::TWPOW>(twreg, tw, j);
     }
+    constexpr bool TWPOW = Tune::TWPOW && KG::TWMODE == TW_REG;
 
     // Per-thread element offsets of its E points relative to the tile base (constant over tiles).
-    unsigned irel[E], orel[E];
+    // PLAIN maps (one block, no uneven slab): offset = base + k * step with a wave-uniform step, no per-point VGPRs.
+    constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE;
+    constexpr int NREL = PLAIN ? 1 : E;
+    unsigned irel[NREL], orel[NREL];
     unsigned ilast = 0, olast = 0;
+    const unsigned istep = (unsigned)(T * imap.stride), ostep = (unsigned)(T * omap.stride);
+    if constexpr (PLAIN) {
+        irel[0] = (unsigned)(j * imap.stride + c * imap.cstride);
+        orel[0] = (unsigned)(j * omap.stride + c * omap.cstride);
+    }
 #pragma unroll
-    for (int k = 0; k < E; ++k) {
+    for (int k = 0; k < (PLAIN ? 0 : E); ++k) {
         const int idx = j + T * k;
-        const int ib = idx / imap.blk, ob = idx / omap.blk;
+        const int ib = idx / imap.blk;
         irel[k] = (unsigned)(ib * imap.blk_stride + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
-        orel[k] = (unsigned)(ob * omap.blk_stride + (idx - ob * omap.blk) * omap.stride + c * omap.cstride);
-        if (GENERAL) {
-            if (ib == imap.nblk - 1) ilast |= 1u << k;
-            if (ob == omap.nblk - 1) olast |= 1u << k;
-        }
+        if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
+        // staged store: thread owns the linear elements tid + GT*k of the [CB][N] result tile
+        const int oc = KG::OSTAGE ? (tid + GT * k) / N : c;
+        const int oidx = KG::OSTAGE ? (tid + GT * k) % N : idx;
+        const int ob = oidx / omap.blk;
+        orel[k] = (unsigned)(ob * omap.blk_stride + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
+        if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
     }
 
     const unsigned tstep = gridDim.x * G;
     for (unsigned t0 = blockIdx.x * G; t0 < ntiles; t0 += tstep) {
         const unsigned tile = t0 + g;
         bool valid = tile < ntiles;
-        const unsigned a = tile / tiles_per_a;
-        const unsigned b = tile - a * tiles_per_a;
+        const unsigned al = tile / tiles_per_a;
+        const unsigned b = tile - al * tiles_per_a;
+        const unsigned a = al + a_first;  // launches over a sub-range of `a` (plane chunks) keep global addressing
         if (GENERAL) valid = valid && ((int)(b * CB) + c < ncols);
         const V* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
         V* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
@@ -223,23 +325,36 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         if (valid) {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                long long off = irel[k];
+                long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
-                v[k] = ip[off];
+                v[k] = gload<Tune::NTL>(ip + off);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] = V{0, 0};
         }
 
-        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE>(v, twr, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW>(v, twr, lds, j, c);
 
+        if constexpr (KG::OSTAGE) {
+            // results (column c, idx = j + T*k) -> LDS [c][N+1] -> linear order, so a wave stores contiguous runs
+            static_assert(!GENERAL || !KG::OSTAGE, "the staged store is a fast-path variant");
+            group_sync<KG::WAVE_LOCAL>();
+#pragma unroll
+            for (int k = 0; k < E; ++k) lds[c * (N + 1) + j + T * k] = v[k];
+            group_sync<KG::WAVE_LOCAL>();
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const int lin = tid + GT * k;
+                v[k] = lds[(lin / N) * (N + 1) + (lin % N)];
+            }
+        }
         if (valid) {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                long long off = orel[k];
+                long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
-                op[off] = v[k];
+                gstore<Tune::NTS>(op + off, v[k]);
             }
         }
     }
@@ -268,11 +383,10 @@ inline hipError_t launch_debug(hipError_t e, const char* what, int lds, int thre
     return e;
 }
 
-template <class V, class P, int CB, int G, int DIR, bool GENERAL>
-hipError_t launch_variant(const FftLaunch& L, hipStream_t stream) {
-    using KG = KernelGeom<V, P, CB, G>;
-    auto kern = fft_tiles_kernel<V, P, CB, G, DIR, GENERAL>;
-    // blocks/CU is a property of the kernel; computed once per process (same for all gfx950 devices).
+template <class V, class P, int CB, int G, int DIR, bool GENERAL, class Tune = TuneDefault>
+hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_per_cu_out = nullptr) {
+    using KG = KernelGeom<V, P, CB, G, Tune>;
+    auto kern = fft_tiles_kernel<V, P, CB, G, DIR, GENERAL, Tune>;
     // Per-device one-time set-up (function attributes are per device context): LDS opt-in and resident blocks per CU.
     static int blocks_per_cu[64] = {0};
     int dev = 0;
@@ -297,6 +411,7 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream) {
         }
         blocks_per_cu[dev] = occ > 0 ? occ : 1;
     }
+    if (blocks_per_cu_out) *blocks_per_cu_out = blocks_per_cu[dev];
     const long long nblocks_needed = (L.ntiles + G - 1) / G;
     long long grid = (long long)device_info().cus * blocks_per_cu[dev];
     if (grid > nblocks_needed) grid = nblocks_needed;
@@ -304,7 +419,7 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream) {
     (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const V*)L.in, (V*)L.out,
                        (const V*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles, (unsigned)L.tiles_per_a,
-                       L.ncols);
+                       L.ncols, (unsigned)L.a_first);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)KG::LDS_BYTES, KG::THREADS);
     return hipSuccess;
@@ -326,15 +441,29 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
     const bool general = L.cols && ((L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0);
     if (!L.cols) {
+        if (L.hints & FFT_HINT_STREAM_IN) {
+            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
+            return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
+        }
         if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
         return launch_variant<V, P, 1, GR, -1, false>(L, stream);
     }
     if constexpr (CBC * P::T <= 1024) {
+        // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
+        using TT = TuneTransposedStore<CBC * P::T * GC>;
+        constexpr bool can_stage = P::S > 1 && (size_t)(P::N + 1) * CBC * GC * sizeof(V) <= 80 * 1024;
+        const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true>(L, stream);
+            if constexpr (can_stage)
+                if (staged) return launch_variant<V, P, CBC, GC, +1, false, TT>(L, stream);
+            if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, TuneStreamOut>(L, stream);
             return launch_variant<V, P, CBC, GC, +1, false>(L, stream);
         }
         if (general) return launch_variant<V, P, CBC, GC, -1, true>(L, stream);
+        if constexpr (can_stage)
+            if (staged) return launch_variant<V, P, CBC, GC, -1, false, TT>(L, stream);
+        if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, TuneStreamIn>(L, stream);
         return launch_variant<V, P, CBC, GC, -1, false>(L, stream);
     } else {
         return hipErrorInvalidValue;

@@ -41,6 +41,12 @@ struct FftLaunch {
     long long   ntiles;
     int         tiles_per_a;
     int         ncols;  // number of valid columns along the tiled dimension (guard for ragged last tile)
+    long long   a_first;  // first `a` this launch covers (plane-chunked launches); ntiles counts tiles from there
+    int         hints;    // FFT_HINT_* cache-policy hints (never change results)
+};
+enum {
+    FFT_HINT_STREAM_IN = 1,   // input is read once and must not displace the cache-resident chunk: non-temporal loads
+    FFT_HINT_STREAM_OUT = 2,  // output goes to a different buffer and is not re-read soon: non-temporal stores
 };
 
 // Column-tile width (elements) the column kernel uses for length n: 128 B per row segment unless LDS-bound.

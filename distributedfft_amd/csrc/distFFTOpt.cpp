@@ -24,6 +24,10 @@
 #include "fft_mpi_3d_api.h"
 
 int main(int argc, char* argv[]) {
+    if (argc == 2 && std::string(argv[1]) == "--device-count") {  // helper for speedTest.sh
+        printf("%d\n", dfft_device_count());
+        return 0;
+    }
     char hostname[256];
     gethostname(hostname, sizeof(hostname));
     printf("PID %d on %s ready for attach\n", getpid(), hostname);  // fftSpeed3d_c2c.cpp:13

@@ -13,8 +13,8 @@ if [ -n "$DFFT_MPIRUN" ]; then
     exec $DFFT_MPIRUN -np "$NP" "$BIN" $2 $3 $4 1
 fi
 
-NGPU=$(ls -d /sys/class/kfd/kfd/topology/nodes/*/ 2>/dev/null | while read n; do
-           [ "$(awk '/simd_count/{print $2}' "$n/properties" 2>/dev/null)" != "0" ] && echo x; done | wc -l)
+NGPU=$("$BIN" --device-count 2>/dev/null | tail -1)
+NGPU=${NGPU:-0}
 if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ]; then
     # fewer GPUs than ranks: drive <MPI-RANK> virtual devices from one process (GPU_COUNT = $NP), sharing the GPUs
     # round-robin like the reference driver's hipSetDevice(globalIdx % devCount) (fftSpeed3d_c2c.cpp:53)
