@@ -413,7 +413,9 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     }
     if (blocks_per_cu_out) *blocks_per_cu_out = blocks_per_cu[dev];
     const long long nblocks_needed = (L.ntiles + G - 1) / G;
-    long long grid = (long long)device_info().cus * blocks_per_cu[dev];
+    int bpc = blocks_per_cu[dev];
+    if (L.blocks_per_cu_limit > 0 && L.blocks_per_cu_limit < bpc) bpc = L.blocks_per_cu_limit;
+    long long grid = (long long)device_info().cus * bpc;
     if (grid > nblocks_needed) grid = nblocks_needed;
     if (grid < 1) return hipSuccess;
     (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)

@@ -43,6 +43,8 @@ struct FftLaunch {
     int         ncols;  // number of valid columns along the tiled dimension (guard for ragged last tile)
     long long   a_first;  // first `a` this launch covers (plane-chunked launches); ntiles counts tiles from there
     int         hints;    // FFT_HINT_* cache-policy hints (never change results)
+    int         blocks_per_cu_limit;  // > 0: cap the persistent grid at this many blocks per CU (leaves room for a
+                                      // kernel running concurrently on another stream)
 };
 enum {
     FFT_HINT_STREAM_IN = 1,   // input is read once and must not displace the cache-resident chunk: non-temporal loads

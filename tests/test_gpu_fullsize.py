@@ -1,0 +1,124 @@
+"""-m gpu: the BASELINE.json configurations at FULL size, checked through size-independent properties (the oracle cannot
+finish these in seconds): separable plane waves -> isolated spikes of height N at the right [yy][z][kx] position of the
+right device, impulse -> plane wave, Parseval checksum, and forward/backward round trip.  P > 1 runs as P virtual devices
+on the one GPU (in-process exchange), i.e. the decomposition, packing and offsets of the real multi-GPU layout.
+
+  C2  256^3 fp64  P=1        512^3 fp64  P=1 and P=4        C4  1024x768x512 fp64  P=8 (radix-3 Y axis, non-cubic)
+  C5  2048x2048x1024 fp32  P=8 (2^32 elements, 64-bit indexing, 2048-point tiles)
+"""
+import math
+import threading
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    pytest.param((256, 256, 256), 1, "f64", id="C2-256^3-fp64-P1"),
+    pytest.param((512, 512, 512), 1, "f64", id="512^3-fp64-P1"),
+    pytest.param((512, 512, 512), 4, "f64", id="C3-512^3-fp64-P4"),
+    pytest.param((1024, 768, 512), 8, "f64", id="C4-1024x768x512-fp64-P8"),
+    pytest.param((2048, 2048, 1024), 8, "f32", id="C5-2048x2048x1024-fp32-P8"),
+]
+TOL = {"f64": 1e-11, "f32": 5e-4}
+
+
+def _slab(n, P, g):
+    blk = -(-n // P)
+    return g * blk, (blk if g < P - 1 else n - (P - 1) * blk)
+
+
+def _run(plans):
+    errs = []
+
+    def work(p):
+        try:
+            p.execute()
+            p.sync()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(p,)) for p in plans]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("N,P,prec", CONFIGS)
+def test_fullsize_properties(gpu, N, P, prec):
+    import torch
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    NT = n0 * n1 * n2
+    cdt = torch.complex128 if prec == "f64" else torch.complex64
+    free, _ = torch.cuda.mem_get_info()
+    need = 0
+    for g in range(P):
+        need += 3 * api.get_max_data_count(n0, n1, n2, P, g == P - 1) * (16 if prec == "f64" else 8)
+    if need * 1.6 > free:
+        pytest.skip(f"needs {need * 1.6 / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} free")
+
+    # three separable plane waves with amplitudes a_m at (kx, ky, kz) chosen to land on different devices / corners
+    waves = [(1.0, (1, 0, 0)), (0.5, (n0 - 1, n1 // 2 + 1, 3)), (0.25, (n0 // 3, n1 - 1, n2 - 1))]
+
+    def axis(n, k, lo, cnt):
+        t = torch.arange(lo, lo + cnt, device=gpu, dtype=torch.float64)
+        ph = 2 * math.pi * ((k * t) % n) / n
+        return torch.complex(torch.cos(ph), torch.sin(ph)).to(cdt)
+
+    comm = api.Comm.local(P) if P > 1 else None
+    ins, outs, plans = [], [], []
+    energy_in = 0.0
+    for g in range(P):
+        x0, xs = _slab(n0, P, g)
+        mc = api.get_max_data_count(n0, n1, n2, P, g == P - 1)
+        a = torch.zeros(mc, dtype=cdt, device=gpu)
+        v = a[:xs * n1 * n2].view(xs, n1, n2)
+        for amp, (kx, ky, kz) in waves:
+            v += amp * axis(n0, kx, x0, xs)[:, None, None] * axis(n1, ky, 0, n1)[None, :, None] * axis(n2, kz, 0, n2)[None, None, :]
+        if g == 0:
+            v[0, 0, 0] += 1.0  # plus an impulse at the origin -> +1 on every output bin
+        energy_in += float((v.real.double() ** 2 + v.imag.double() ** 2).sum().item())
+        b = torch.zeros(mc, dtype=cdt, device=gpu)
+        ins.append(a)
+        outs.append(b)
+        plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, api.FORWARD, api.PLAN_INPUT_FROM_IN))
+    _run(plans)
+
+    # expected: 1 everywhere (impulse) + a_m * N at (kx, ky, kz); layout out_d[yy][z][kx]
+    tol = TOL[prec] * NT
+    energy_out = 0.0
+    for d in range(P):
+        y0, ys = _slab(n1, P, d)
+        o = outs[d][:ys * n2 * n0].view(ys, n2, n0)
+        energy_out += float((o.real.double() ** 2 + o.imag.double() ** 2).sum().item())
+        o = o - 1.0
+        for amp, (kx, ky, kz) in waves:
+            if y0 <= ky < y0 + ys:
+                got = o[ky - y0, kz, kx]
+                assert abs(complex(got.item()) - amp * NT) < tol, (d, kx, ky, kz, got.item())
+                o[ky - y0, kz, kx] -= amp * NT
+        resid = float(o.abs().max().item())
+        assert resid < tol, f"device {d}: residual {resid:.3e} (tol {tol:.3e})"
+        del o
+    # Parseval: sum |X|^2 = N sum |x|^2 (a checksum over every output element)
+    assert abs(energy_out / (NT * energy_in) - 1.0) < (1e-10 if prec == "f64" else 1e-4)
+
+    # round trip: backward(forward(x)) / N == x
+    for p in plans:
+        p.destroy()
+    backs, bplans = [], []
+    for g in range(P):
+        c = torch.zeros_like(ins[g])
+        backs.append(c)
+        bplans.append(api.Plan(n0, n1, n2, outs[g], c, comm, g, P, api.BACKWARD, api.PLAN_INPUT_FROM_IN))
+    _run(bplans)
+    for g in range(P):
+        x0, xs = _slab(n0, P, g)
+        cnt = xs * n1 * n2
+        err = float((backs[g][:cnt] / NT - ins[g][:cnt]).abs().max().item())
+        assert err < (1e-11 if prec == "f64" else 2e-4), f"round trip device {g}: {err:.3e}"
+    for p in bplans:
+        p.destroy()
+    if comm:
+        comm.destroy()
