@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--size", type=parse_size, default=(512, 512, 512))
     ap.add_argument("--precision", choices=["fp64", "fp32"], default="fp64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-plane check only (CPU tests): rendezvous, id broadcast, slab bookkeeping; no GPU work")
     ap.add_argument("--unfused", action="store_true", help="reference stage structure (separate pack / transpose)")
     args = ap.parse_args()
 
@@ -95,10 +97,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    dev = torch.device("cuda", torch.cuda.current_device())
+    if not args.dry_run:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dev = torch.device("cuda", torch.cuda.current_device())
 
     P = world
     comm = None
@@ -107,9 +110,25 @@ def main():
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
-            uid = torch.frombuffer(bytearray(api.Comm.rccl_unique_id()), dtype=torch.uint8).clone()
+            raw = bytes(range(128)) if args.dry_run else api.Comm.rccl_unique_id()
+            uid = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
         dist.broadcast(uid, src=0)
-        comm = api.Comm.rccl(bytes(uid.tolist()), P, rank)
+        uid_bytes = bytes(uid.tolist())
+        if not args.dry_run:
+            comm = api.Comm.rccl(uid_bytes, P, rank)
+    if args.dry_run:
+        tot, inr, counts = api.fft_mpi_init(args.size, 1, mpi_size=P, mpi_rank=rank)
+        lay = api.exchange_layout(*args.size, P, rank, api.FORWARD)
+        ok = tot == P and (P == 1 or uid_bytes == bytes(range(128)))
+        t = torch.tensor([float(sum(lay.scount))], dtype=torch.float64)
+        if P > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "ok": bool(ok), "n_gpus": P, "elements_exchanged": t.item(),
+                              "local_count": counts[0]}), flush=True)
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -137,6 +156,9 @@ def main():
     del re, im
     b = torch.zeros(max_count, dtype=cdt, device=dev)
     flags = api.PLAN_INPUT_FROM_IN | (api.PLAN_UNFUSED if args.unfused else 0)
+    overlap = P > 1 and not args.unfused and os.environ.get("DFFT_BENCH_OVERLAP", "1") != "0"
+    if overlap:
+        flags |= api.PLAN_OVERLAP  # exchange parts on a second stream behind the plane-chunked Z+Y passes
     plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
 
     for _ in range(args.warmup):
@@ -247,7 +269,9 @@ def main():
             "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
             "config": {"workload": f"{n0}x{n1}x{n2} C2C {args.precision} forward, slab decomposition over {P} GPU(s), "
                                    f"{'fused' if not args.unfused else 'unfused'} pipeline, input resident in HBM",
-                       "parallelism": f"slab{P}", "exchange": "none (P=1)" if P == 1 else "RCCL grouped send/recv over xGMI"},
+                       "parallelism": f"slab{P}",
+                       "exchange": "none (P=1)" if P == 1 else "RCCL grouped send/recv over xGMI" +
+                                   (", X-plane parts overlapped with t0 on a second stream (stages_ms.t2 = exposed part)" if overlap else "")},
             "max_error": rt_err / 1e7, "roundtrip_abs_error": rt_err,
             "stages_ms": {"t0": round(float(stage[0]) * 1e3, 4), "t1": round(float(stage[1]) * 1e3, 4),
                           "t2": round(float(stage[2]) * 1e3, 4), "t3": round(float(stage[3]) * 1e3, 4)},

@@ -2,12 +2,15 @@
 //
 // Replaces slabAlltoall (fft_mpi_3d_api.cpp:610-672): the reference moves chunk (src -> dst) with hipMemcpyPeerAsync
 // inside a process and with MPI_Isend/Irecv on device pointers (UCX) between processes.  Here:
-//   RCCL  communicator : one grouped ncclSend/ncclRecv per peer on the plan's stream (xGMI point-to-point: each
+//   RCCL  communicator : one grouped ncclSend/ncclRecv per peer on the given stream (xGMI point-to-point: each
 //                        (src,dst) pair has its own link, so the whole exchange is bounded by the pair chunk
 //                        S*N/P^2 over ~153 GB/s), self chunk by device copy.
 //   LOCAL communicator : P device-threads of one process; peer copies between the plans' buffers with the same
 //                        barrier discipline as the reference's `#pragma omp barrier`s (fft_mpi_3d_api.cpp:190,195).
 //                        Also used with P virtual devices on one physical GPU for single-GPU parity tests.
+// Because the Y pass writes the packed [dest][x][y_dest][N2] layout directly, every message is one contiguous block on
+// both sides, and so is any sub-range of its X planes: comm_exchange_part moves planes [k*cp, (k+1)*cp) of every
+// source slab, which lets the plan pipeline t2 behind the plane-chunked t0.
 #include <rccl/rccl.h>
 
 #include <condition_variable>
@@ -24,7 +27,8 @@ struct dfft_comm_s {
     std::condition_variable cv;
     int                     arrived = 0;
     unsigned long           generation = 0;
-    std::vector<void*>      recvbufs;
+    std::vector<void*>      recvbufs;  // [slot * P + device]: slot 0 = forward plans, 1 = backward plans (the reference
+                                       // shares one node_data[] between both and aliases them, fftSpeed3d_c2c.cpp:74,80)
     std::vector<int>        devices;
     // rccl
     ncclComm_t nccl = nullptr;
@@ -51,11 +55,11 @@ int comm_thread_barrier(dfft_comm_t c) {
     return DFFT_OK;
 }
 
-int comm_register(dfft_comm_t c, int me, void* recvbuf, int device) {
-    if (me < 0 || me >= c->P) return fail(DFFT_EINVAL, "comm_register: device index out of range");
+int comm_register(dfft_comm_t c, int me, int slot, void* recvbuf, int device) {
+    if (me < 0 || me >= c->P || slot < 0 || slot > 1) return fail(DFFT_EINVAL, "comm_register: index out of range");
     if (c->kind == 0) {
         std::lock_guard<std::mutex> lk(c->m);
-        c->recvbufs[me] = recvbuf;
+        c->recvbufs[(size_t)slot * c->P + me] = recvbuf;
         c->devices[me] = device;
     } else {
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the RCCL rank");
@@ -63,15 +67,48 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device) {
     return DFFT_OK;
 }
 
-int comm_unregister(dfft_comm_t c, int me) {
-    if (c->kind == 0 && me >= 0 && me < c->P) {
+int comm_unregister(dfft_comm_t c, int me, int slot, void* recvbuf) {
+    if (c->kind == 0 && me >= 0 && me < c->P && slot >= 0 && slot <= 1) {
         std::lock_guard<std::mutex> lk(c->m);
-        c->recvbufs[me] = nullptr;
+        void*& r = c->recvbufs[(size_t)slot * c->P + me];
+        if (r == recvbuf) r = nullptr;
     }
     return DFFT_OK;
 }
 
-static int exchange_local(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
+namespace {
+// One round of messages: per peer, element offsets/counts on the send side, the receive side, and (push-style local
+// exchange) the offset inside the peer's receive buffer.
+struct Round {
+    std::vector<long long> so, sc, ro, rc, doff;
+};
+
+Round whole_round(const ExchangeDesc& x) { return Round{x.soffset, x.scount, x.roffset, x.rcount, x.doffset}; }
+
+Round part_round(const ExchangeDesc& x, int k, long long cp) {
+    Round r;
+    r.so.resize(x.P);
+    r.sc.resize(x.P);
+    r.ro.resize(x.P);
+    r.rc.resize(x.P);
+    r.doff.resize(x.P);
+    long long mx0, mnx;
+    part_range(x.xsize[x.me], cp, k, &mx0, &mnx);
+    for (int q = 0; q < x.P; ++q) {
+        // my planes [mx0, mx0+mnx) of chunk(me -> q)
+        r.so[q] = x.soffset[q] + mx0 * x.ysize[q] * x.n2;
+        r.sc[q] = mnx * x.ysize[q] * x.n2;
+        r.doff[q] = x.doffset[q] + mx0 * x.ysize[q] * x.n2;
+        // q's planes [qx0, qx0+qnx) of chunk(q -> me)
+        long long qx0, qnx;
+        part_range(x.xsize[q], cp, k, &qx0, &qnx);
+        r.ro[q] = x.roffset[q] + qx0 * x.ysize[x.me] * x.n2;
+        r.rc[q] = qnx * x.ysize[x.me] * x.n2;
+    }
+    return r;
+}
+
+int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
     const size_t eb = elem_bytes(x.dtype);
     // every device has finished producing its send buffer and consuming its receive buffer
     DFFT_HIP_TRY(hipStreamSynchronize(stream));
@@ -80,20 +117,20 @@ static int exchange_local(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stre
     DFFT_HIP_TRY(hipGetDevice(&mydev));
     for (int i = 0; i < x.P; ++i) {
         const int peer = (x.me + i) % x.P;  // stagger the targets like a rotation schedule
-        if (x.scount[peer] == 0) continue;
+        if (r.sc[peer] == 0) continue;
         void* dstbase;
         int   dstdev;
         {
             std::lock_guard<std::mutex> lk(c->m);
-            dstbase = c->recvbufs[peer];
+            dstbase = c->recvbufs[(size_t)x.slot * c->P + peer];
             dstdev = c->devices[peer];
         }
         if (!dstbase) return fail(DFFT_ECOMM, "local exchange: peer plan is not registered");
         // chunk(me -> peer) lands in peer's bufferDev1 at the offset reserved there for source `me`
         // (recv_offset, fft_mpi_3d_api.cpp:618-625)
-        char*       dst = (char*)dstbase + (size_t)x.doffset[peer] * eb;
-        const char* src = (const char*)x.sendbuf + (size_t)x.soffset[peer] * eb;
-        const size_t bytes = (size_t)x.scount[peer] * eb;
+        char*        dst = (char*)dstbase + (size_t)r.doff[peer] * eb;
+        const char*  src = (const char*)x.sendbuf + (size_t)r.so[peer] * eb;
+        const size_t bytes = (size_t)r.sc[peer] * eb;
         if (dstdev == mydev) DFFT_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
         else DFFT_HIP_TRY(hipMemcpyPeerAsync(dst, dstdev, src, mydev, bytes, stream));
     }
@@ -102,38 +139,45 @@ static int exchange_local(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stre
     return DFFT_OK;
 }
 
-static int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
-    const size_t eb = elem_bytes(x.dtype);
+int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
+    const size_t         eb = elem_bytes(x.dtype);
     const ncclDataType_t ty = x.dtype == DFFT_F64 ? ncclDouble : ncclFloat;
     // self chunk: plain device copy (no link involved)
-    if (x.scount[x.me] > 0)
-        DFFT_HIP_TRY(hipMemcpyAsync((char*)x.recvbuf + (size_t)x.roffset[x.me] * eb,
-                                    (const char*)x.sendbuf + (size_t)x.soffset[x.me] * eb, (size_t)x.scount[x.me] * eb,
-                                    hipMemcpyDeviceToDevice, stream));
+    if (r.sc[x.me] > 0)
+        DFFT_HIP_TRY(hipMemcpyAsync((char*)x.recvbuf + (size_t)r.ro[x.me] * eb, (const char*)x.sendbuf + (size_t)r.so[x.me] * eb,
+                                    (size_t)r.sc[x.me] * eb, hipMemcpyDeviceToDevice, stream));
     if (x.P == 1) return DFFT_OK;
-    ncclResult_t r = ncclGroupStart();
-    if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(r));
+    ncclResult_t rc = ncclGroupStart();
+    if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(rc));
     for (int i = 1; i < x.P; ++i) {
         const int to = (x.me + i) % x.P, from = (x.me - i + x.P) % x.P;
-        if (x.scount[to] > 0) {
-            r = ncclSend((const char*)x.sendbuf + (size_t)x.soffset[to] * eb, (size_t)x.scount[to] * 2, ty, to, c->nccl,
-                         stream);
-            if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(r));
+        if (r.sc[to] > 0) {
+            rc = ncclSend((const char*)x.sendbuf + (size_t)r.so[to] * eb, (size_t)r.sc[to] * 2, ty, to, c->nccl, stream);
+            if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(rc));
         }
-        if (x.rcount[from] > 0) {
-            r = ncclRecv((char*)x.recvbuf + (size_t)x.roffset[from] * eb, (size_t)x.rcount[from] * 2, ty, from, c->nccl,
-                         stream);
-            if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(r));
+        if (r.rc[from] > 0) {
+            rc = ncclRecv((char*)x.recvbuf + (size_t)r.ro[from] * eb, (size_t)r.rc[from] * 2, ty, from, c->nccl, stream);
+            if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(rc));
         }
     }
-    r = ncclGroupEnd();
-    if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupEnd: ") + ncclGetErrorString(r));
+    rc = ncclGroupEnd();
+    if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupEnd: ") + ncclGetErrorString(rc));
     return DFFT_OK;
 }
+}  // namespace
 
 int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
-    if (c->kind == 0) return exchange_local(c, x, stream);
-    return exchange_rccl(c, x, stream);
+    const Round r = whole_round(x);
+    if (c->kind == 0) return exchange_local(c, x, r, stream);
+    return exchange_rccl(c, x, r, stream);
+}
+
+int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp, hipStream_t stream) {
+    if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0)
+        return fail(DFFT_EINVAL, "comm_exchange_part: descriptor has no plane geometry");
+    const Round r = part_round(x, k, cp);
+    if (c->kind == 0) return exchange_local(c, x, r, stream);
+    return exchange_rccl(c, x, r, stream);
 }
 
 }  // namespace dfft
@@ -147,7 +191,7 @@ int dfft_comm_create_local(int total_devices, dfft_comm_t* comm) {
     dfft_comm_s* c = new dfft_comm_s;
     c->kind = 0;
     c->P = total_devices;
-    c->recvbufs.assign(total_devices, nullptr);
+    c->recvbufs.assign(2 * (size_t)total_devices, nullptr);
     c->devices.assign(total_devices, 0);
     *comm = c;
     return DFFT_OK;

@@ -40,18 +40,37 @@ int get_twiddles(int n, int dtype, const void** table);
 struct ExchangeDesc {
     int                    dtype;
     int                    P, me;
+    int                    slot = 0;  // 0 forward, 1 backward: which registered receive buffer of the peers to push into
     void*                  sendbuf;  // bufferDev2
     void*                  recvbuf;  // bufferDev1 (this device's; peers' are looked up through the communicator)
     std::vector<long long> scount, soffset, rcount, roffset;  // elements, indexed by peer
     std::vector<long long> doffset;  // where chunk(me -> peer) lands inside peer's recvbuf (push-style local exchange)
+    // forward exchange only: what is needed to cut every message along X into plane chunks (t0/t2 overlap).
+    // chunk(src -> dst) is [x in src][y in dst][N2] with x slowest, so planes [x0, x0+nx) of it are contiguous on both
+    // sides: + x0 * ysize[dst] * n2 elements.
+    std::vector<long long> xsize, ysize;  // planes owned by each device before / rows owned after the transform
+    long long              n2 = 0;
 };
 
-int comm_register(dfft_comm_t comm, int me, void* recvbuf, int device);
-int comm_unregister(dfft_comm_t comm, int me);
+// Range of planes device g contributes to exchange part k when every device cuts its slab into parts of `cp` planes.
+inline void part_range(long long xs_g, long long cp, int k, long long* x0, long long* nx) {
+    long long a = (long long)k * cp, b = a + cp;
+    if (a > xs_g) a = xs_g;
+    if (b > xs_g) b = xs_g;
+    *x0 = a;
+    *nx = b - a;
+}
+
+// slot: 0 for forward plans, 1 for backward plans (each direction has its own receive buffer per device)
+int comm_register(dfft_comm_t comm, int me, int slot, void* recvbuf, int device);
+int comm_unregister(dfft_comm_t comm, int me, int slot, void* recvbuf);
 int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl
 int comm_size(dfft_comm_t comm);
 // Local: host-synchronising collective (thread barrier + peer copies); RCCL: enqueued on `stream`.
 int comm_exchange(dfft_comm_t comm, const ExchangeDesc& x, hipStream_t stream);
+// Forward exchange restricted to part k (planes [k*cp, (k+1)*cp) of every source slab); the parts of k = 0..K-1 together
+// move exactly what comm_exchange moves.  RCCL: enqueued on `stream`; LOCAL: host-synchronising like comm_exchange.
+int comm_exchange_part(dfft_comm_t comm, const ExchangeDesc& x, int k, long long cp, hipStream_t stream);
 // Thread barrier over the P local device-threads (no-op for RCCL communicators).
 int comm_thread_barrier(dfft_comm_t comm);
 

@@ -152,6 +152,12 @@ struct dfft_plan_s {
     ExchangeDesc xd;
     int         cb_y, cb_x;  // column-tile widths of the Y and X passes
     long long   chunk_planes;  // planes per Z+Y chunk (Infinity-Cache blocking); 0 = whole slab in one launch pair
+    // DFFT_PLAN_OVERLAP (forward, P > 1): exchange parts on a second stream behind the plane-chunked Z+Y passes
+    long long               part_planes = 0;  // planes per exchange part, identical on every rank; 0 = overlap off
+    hipStream_t             stream2 = nullptr;
+    void*                   rbuf = nullptr;  // dedicated receive buffer of the overlapped exchange
+    hipEvent_t              join_ev = nullptr;
+    std::vector<hipEvent_t> part_ev;
 };
 
 static int fill_exchange(dfft_plan_s* p) {
@@ -166,6 +172,13 @@ static int fill_exchange(dfft_plan_s* p) {
     x.rcount.assign(P, 0);
     x.roffset.assign(P, 0);
     x.doffset.assign(P, 0);
+    x.xsize.assign(P, 0);
+    x.ysize.assign(P, 0);
+    x.n2 = n2;
+    for (int q = 0; q < P; ++q) {
+        x.xsize[q] = p->sx.size(q);
+        x.ysize[q] = p->sy.size(q);
+    }
     for (int q = 0; q < P; ++q) {
         if (p->direction == DFFT_FORWARD) {
             // chunk(me -> q) = x in me's slab, y in q's slab          
@@ -319,6 +332,39 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const bool      y_packs = fused && p->P > 1;
+    if (y_packs && (p->flags & DFFT_PLAN_OVERLAP) && p->part_planes > 0) {
+        // ---- t0 pipelined against t2: the exchange of plane part k (stream2) runs while the Z+Y passes of part k+1
+        // (stream) compute.  Any X-plane sub-range of the packed send layout is contiguous on both sides, so the parts
+        // need no extra packing (dfft_exchange.cpp).  All ranks cut their slabs with the same part size.
+        const bool rccl = comm_kind(p->comm) == 1;
+        const int  K = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
+        for (int k = 0; k < K; ++k) {
+            long long x0, nx;
+            part_range(p->xs, p->part_planes, k, &x0, &nx);
+            if (nx > 0) {
+                DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
+                                  zsrc != p->buf1 ? FFT_HINT_STREAM_IN : 0));
+                DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT));
+            }
+            if (rccl) {
+                DFFT_HIP_TRY(hipEventRecord(p->part_ev[k], p->stream));
+                DFFT_HIP_TRY(hipStreamWaitEvent(p->stream2, p->part_ev[k], 0));
+                DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, p->stream2));
+            } else {
+                DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, p->stream));  // host-synchronising
+            }
+        }
+        DFFT_TRY(clk.end_stage());
+        DFFT_TRY(clk.end_stage());  // t1 folded into t0
+        if (rccl) {
+            DFFT_HIP_TRY(hipEventRecord(p->join_ev, p->stream2));
+            DFFT_HIP_TRY(hipStreamWaitEvent(p->stream, p->join_ev, 0));
+        }
+        DFFT_TRY(clk.end_stage());  // t2 = the part of the exchange that was not hidden behind t0
+        DFFT_TRY(launch_x(p, p->rbuf, p->buf2));
+        DFFT_TRY(clk.end_stage());
+        return DFFT_OK;
+    }
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     const bool      chunked = cp < p->xs;
     for (long long x0 = 0; x0 < p->xs; x0 += cp) {
@@ -601,6 +647,25 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
+    if ((flags & DFFT_PLAN_OVERLAP) && total_devices > 1 && direction == DFFT_FORWARD && !(flags & DFFT_PLAN_UNFUSED)) {
+        // parts: DFFT_OVERLAP_PARTS (default 4) per slab, never larger than one Infinity-Cache chunk; derived from the
+        // global block size ceil(N0/P) so that every rank cuts identically
+        long long   parts = 4;
+        const char* pe = getenv("DFFT_OVERLAP_PARTS");
+        if (pe && atoll(pe) > 0) parts = atoll(pe);
+        long long pp = (p->sx.blk + parts - 1) / parts;
+        const long long plane_bytes = n1 * n2 * (long long)elem_bytes(dtype);
+        const long long cache_planes = std::max(1ll, (256ll << 20) / plane_bytes);
+        if (pp > cache_planes) pp = cache_planes;
+        if (pp < 1) pp = 1;
+        p->part_planes = pp;
+        const int K = (int)((p->sx.blk + pp - 1) / pp);
+        p->part_ev.assign(K, nullptr);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->join_ev, hipEventDisableTiming);
+        for (auto& ev : p->part_ev)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         dfft_plan_destroy(p);
         return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
@@ -608,8 +673,19 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     fill_exchange(p);
     p->xd.sendbuf = p->buf2;
     p->xd.recvbuf = p->buf1;
+    p->xd.slot = direction == DFFT_FORWARD ? 0 : 1;
+    if (p->part_planes > 0) {
+        // overlap mode: parts arrive while later planes are still being transformed in bufferDev1, so the exchange
+        // needs a receive buffer of its own (one more slab in HBM; 288 GB makes that a non-issue)
+        e = hipMalloc(&p->rbuf, bytes);
+        if (e != hipSuccess) {
+            dfft_plan_destroy(p);
+            return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+        }
+        p->xd.recvbuf = p->rbuf;
+    }
     if (comm) {
-        int rc = comm_register(comm, global_idx, p->buf1, p->device);  // nodeDataDev[loc] = bufferDev1, :80
+        int rc = comm_register(comm, global_idx, p->xd.slot, p->xd.recvbuf, p->device);  // nodeDataDev[loc] = bufferDev1, :80
         if (rc) {
             dfft_plan_destroy(p);
             return rc;
@@ -673,7 +749,7 @@ int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
     if (!plan || !t) return fail(DFFT_EINVAL, "dfft_kernel_times: bad arguments");
     if (plan->host_timed) return fail(DFFT_EINVAL, "dfft_kernel_times: needs an execute without DFFT_EXEC_SYNC_STAGES");
     if (plan->flags & DFFT_PLAN_UNFUSED) return fail(DFFT_EINVAL, "dfft_kernel_times: fused plans only");
-    if (plan->chunk_planes > 0)
+    if (plan->chunk_planes > 0 || plan->part_planes > 0)
         return fail(DFFT_EINVAL, "dfft_kernel_times: Z and Y launches are interleaved per cache chunk (set DFFT_CHUNK_MB=0)");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
     float z = 0, y = 0, x = 0;
@@ -695,11 +771,17 @@ int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
 int dfft_plan_destroy(dfft_plan_t plan) {
     if (!plan) return DFFT_OK;
     if (plan->stream) hipStreamSynchronize(plan->stream);
-    if (plan->comm) comm_unregister(plan->comm, plan->me);
+    if (plan->stream2) hipStreamSynchronize(plan->stream2);
+    if (plan->comm) comm_unregister(plan->comm, plan->me, plan->xd.slot, plan->xd.recvbuf);
     for (auto& e : plan->ev)
         if (e) hipEventDestroy(e);
+    for (auto& e : plan->part_ev)
+        if (e) hipEventDestroy(e);
+    if (plan->join_ev) hipEventDestroy(plan->join_ev);
+    if (plan->stream2) hipStreamDestroy(plan->stream2);
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
+    if (plan->rbuf) hipFree(plan->rbuf);
     delete plan;
     return DFFT_OK;
 }

@@ -110,3 +110,22 @@ def test_tcp_rendezvous(native_lib, world):
         o, e = p.communicate(timeout=120)
         assert p.returncode == 0, e[-2000:]
         assert f"BOOT_OK {r} {world}" in o
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_bench_control_plane_dry_run(native_lib, world):
+    """bench.py's multi-rank plumbing (torchrun-style env, gloo rendezvous, 128-byte id broadcast, slab bookkeeping),
+    without touching a GPU: `--dry-run` stops before any device work."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--dry-run"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["ok"] and d["n_gpus"] == world and d["elements_exchanged"] == 512 ** 3 and d["local_count"] == 512 ** 3 // world
