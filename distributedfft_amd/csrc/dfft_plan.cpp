@@ -366,7 +366,8 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         return DFFT_OK;
     }
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
-    const bool      chunked = cp < p->xs;
+    // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
+    const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
     for (long long x0 = 0; x0 < p->xs; x0 += cp) {
         const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
@@ -445,7 +446,8 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     }
     const bool      y_unpacks = fused && p->P > 1;
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
-    const bool      chunked = cp < p->xs;
+    // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
+    const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
     for (long long x0 = 0; x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0));
