@@ -46,26 +46,39 @@ struct TuneDefault {
     static constexpr int MIN_WAVES = 0;    // amdgpu_waves_per_eu lower bound (0 = let the compiler decide)
     static constexpr int CB_OVERRIDE = 0;  // columns per tile (0 = cols_per_tile())
     static constexpr bool PLAIN = false;   // single-block address maps: offsets = base + k*step (no per-point VGPRs)
+    static constexpr bool PREFETCH = false; // issue the next tile's loads before processing the current one (+E complex VGPRs)
 };
 
 // Column kernel whose store side is the transposed one ([..][z][kx], kx fastest: the forward X pass).  Measured on
 // MI355X at 512^3 fp64 (tools/kbench, profiles/): direct 128-byte-segment stores 1.20 ms; results staged through LDS so
 // each wave stores 1 KiB runs + two resident blocks per CU (<= 128 VGPRs) + streaming (non-temporal) access 0.92 ms.
-template <int THREADS> struct TuneTransposedStore {
+// Adding a register prefetch of the next tile (the block then overlaps HBM latency with its own barriers) beats holding
+// the kernel to 128 VGPRs for a second resident block: 0.95 -> 0.90 ms.
+struct TuneTransposedStore {
     static constexpr bool TWPOW = true;
     static constexpr bool OSTAGE = true;
     static constexpr bool NTL = true;
     static constexpr bool NTS = true;
-    static constexpr int MIN_WAVES = THREADS >= 512 ? 4 : 0;
+    static constexpr int MIN_WAVES = 0;
     static constexpr int CB_OVERRIDE = 0;
     static constexpr bool PLAIN = false;
+    static constexpr bool PREFETCH = true;
+};
+
+// Column kernel default: the next tile's loads are issued before the current tile's exchanges (0.945 -> 0.869 ms on the
+// 512^3 fp64 Y pass; no gain for the barrier-free row kernel, which keeps TuneDefault).
+struct TuneCols : TuneDefault {
+    static constexpr bool PREFETCH = true;
 };
 
 // Cache-policy variants for the Infinity-Cache-blocked Z+Y stage (execute_forward/backward in dfft_plan.cpp).
 struct TuneStreamIn : TuneDefault {
     static constexpr bool NTL = true;
 };
-struct TuneStreamOut : TuneDefault {
+struct TuneColsStreamIn : TuneCols {
+    static constexpr bool NTL = true;
+};
+struct TuneColsStreamOut : TuneCols {
     static constexpr bool NTS = true;
 };
 
@@ -311,6 +324,34 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
     }
 
     const unsigned tstep = gridDim.x * G;
+    // loads the E points of the tile group starting at t into dst (zeros for tiles / columns past the end)
+    auto load_tile = [&](unsigned t, V* dst) {
+        const unsigned tile = t + g;
+        bool ok = tile < ntiles;
+        const unsigned al = tile / tiles_per_a;
+        const unsigned b = tile - al * tiles_per_a;
+        const unsigned a = al + a_first;
+        if (GENERAL) ok = ok && ((int)(b * CB) + c < ncols);
+        const V* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
+                if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
+                dst[k] = gload<Tune::NTL>(ip + off);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) dst[k] = V{0, 0};
+        }
+    };
+    // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
+    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= 32) && KG::THREADS <= 512;
+    V v[E];
+    V vnext[PREFETCH ? E : 1];
+    if constexpr (PREFETCH) {
+        if (blockIdx.x * G < ntiles) load_tile(blockIdx.x * G, v);
+    }
     for (unsigned t0 = blockIdx.x * G; t0 < ntiles; t0 += tstep) {
         const unsigned tile = t0 + g;
         bool valid = tile < ntiles;
@@ -318,20 +359,13 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         const unsigned b = tile - al * tiles_per_a;
         const unsigned a = al + a_first;  // launches over a sub-range of `a` (plane chunks) keep global addressing
         if (GENERAL) valid = valid && ((int)(b * CB) + c < ncols);
-        const V* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
         V* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
 
-        V v[E];
-        if (valid) {
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
-                if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
-                v[k] = gload<Tune::NTL>(ip + off);
-            }
+        if constexpr (PREFETCH) {
+            // issue the next tile's HBM loads now; they complete underneath this tile's exchanges and stores
+            if (t0 + tstep < ntiles) load_tile(t0 + tstep, vnext);
         } else {
-#pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = V{0, 0};
+            load_tile(t0, v);
         }
 
         run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW>(v, twr, lds, j, c);
@@ -356,6 +390,10 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
                 gstore<Tune::NTS>(op + off, v[k]);
             }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = vnext[k];
         }
     }
 }
@@ -452,21 +490,21 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream
     }
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
-        using TT = TuneTransposedStore<CBC * P::T * GC>;
+        using TT = TuneTransposedStore;
         constexpr bool can_stage = P::S > 1 && (size_t)(P::N + 1) * CBC * GC * sizeof(V) <= 80 * 1024;
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
         if (L.dir > 0) {
-            if (general) return launch_variant<V, P, CBC, GC, +1, true>(L, stream);
+            if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
             if constexpr (can_stage)
                 if (staged) return launch_variant<V, P, CBC, GC, +1, false, TT>(L, stream);
-            if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, TuneStreamOut>(L, stream);
-            return launch_variant<V, P, CBC, GC, +1, false>(L, stream);
+            if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, TuneColsStreamOut>(L, stream);
+            return launch_variant<V, P, CBC, GC, +1, false, TuneCols>(L, stream);
         }
-        if (general) return launch_variant<V, P, CBC, GC, -1, true>(L, stream);
+        if (general) return launch_variant<V, P, CBC, GC, -1, true, TuneCols>(L, stream);
         if constexpr (can_stage)
             if (staged) return launch_variant<V, P, CBC, GC, -1, false, TT>(L, stream);
-        if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, TuneStreamIn>(L, stream);
-        return launch_variant<V, P, CBC, GC, -1, false>(L, stream);
+        if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, TuneColsStreamIn>(L, stream);
+        return launch_variant<V, P, CBC, GC, -1, false, TuneCols>(L, stream);
     } else {
         return hipErrorInvalidValue;
     }

@@ -31,6 +31,7 @@ template <bool OSTAGE_, bool NTL_, bool NTS_, int MINW_> struct Tune {
     static constexpr int MIN_WAVES = MINW_;
     static constexpr int CB_OVERRIDE = 0;
     static constexpr bool PLAIN = false;
+    static constexpr bool PREFETCH = false;
 };
 using P512 = Plan<512, 8, 8, 8, 8>;
 
