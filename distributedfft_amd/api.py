@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Tuple
 
 from . import _lib as L
 from ._lib import (BACKWARD, EXEC_ASYNC, EXEC_PRINT, EXEC_SYNC_STAGES, F32, F64, FORWARD, PLAN_DEFAULT,  # noqa: F401
-                   PLAN_INPUT_FROM_IN, PLAN_OVERLAP, PLAN_UNFUSED, DfftError)
+                   PLAN_INPUT_FROM_IN, PLAN_NATURAL, PLAN_OVERLAP, PLAN_UNFUSED, DfftError)
 
 
 def _ll3(N: Sequence[int]):

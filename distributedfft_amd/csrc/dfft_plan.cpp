@@ -150,6 +150,7 @@ struct dfft_plan_s {
     double      host_t[4];
     bool        host_timed;
     ExchangeDesc xd;
+    ExchangeDesc xd2;        // DFFT_PLAN_NATURAL: the second (Y -> X) exchange
     int         cb_y, cb_x;  // column-tile widths of the Y and X passes
     long long   chunk_planes;  // planes per Z+Y chunk (Infinity-Cache blocking); 0 = whole slab in one launch pair
     // DFFT_PLAN_OVERLAP (forward, P > 1): exchange parts on a second stream behind the plane-chunked Z+Y passes
@@ -160,10 +161,9 @@ struct dfft_plan_s {
     std::vector<hipEvent_t> part_ev;
 };
 
-static int fill_exchange(dfft_plan_s* p) {
+static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
     const int       P = p->P, me = p->me;
     const long long n2 = p->N[2];
-    ExchangeDesc&   x = p->xd;
     x.dtype = p->dtype;
     x.P = P;
     x.me = me;
@@ -180,7 +180,7 @@ static int fill_exchange(dfft_plan_s* p) {
         x.ysize[q] = p->sy.size(q);
     }
     for (int q = 0; q < P; ++q) {
-        if (p->direction == DFFT_FORWARD) {
+        if (direction == DFFT_FORWARD) {
             // chunk(me -> q) = x in me's slab, y in q's slab          
             x.scount[q] = p->sx.size(me) * p->sy.size(q) * n2;
             x.soffset[q] = (long long)q * p->sx.size(me) * p->sy.blk * n2;   // packed [d][xl][yl_d][N2]
@@ -249,7 +249,8 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
 }
 
 // X pass.  Slab side: [N0][ys][N2] (x slowest).  Transposed side: [ys][N2][N0] (kx fastest).
-static int launch_x(dfft_plan_s* p, const void* in, void* out) {
+// keep_slab: store [x][ys][N2] again instead of the transposed [ys][N2][kx] (natural-order plans)
+static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = false) {
     const int       n0 = (int)p->N[0];
     const long long n2 = p->N[2];
     const void*     tw = nullptr;
@@ -269,7 +270,10 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out) {
     TileMap slab_tile{n2, 1};
     AxisMap tr = plain_axis(n0, 1, n0);
     TileMap tr_tile{n2 * (long long)n0, (long long)n0};
-    if (p->direction == DFFT_FORWARD) {
+    if (keep_slab) {
+        L.imap = L.omap = slab;
+        L.itile = L.otile = slab_tile;
+    } else if (p->direction == DFFT_FORWARD) {
         L.imap = slab;
         L.itile = slab_tile;
         L.omap = tr;
@@ -411,6 +415,38 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     return DFFT_OK;
 }
 
+// DFFT_PLAN_NATURAL: input AND output are the caller's natural X-slab layout [xs][N1][N2] (the un-transposed output the
+// reference declares but never implements, fft_mpi_local_size_3d / SURVEY 8f-2).  The same sequence serves both
+// directions (the kernels take the sign): Z, Y(+pack) | exchange X->Y | X in slab layout | exchange Y->X | unpack.
+static int execute_natural(dfft_plan_s* p, bool sync) {
+    const long long n1 = p->N[1], n2 = p->N[2];
+    StageClock      clk{p, sync};
+    DFFT_TRY(clk.begin());
+    const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
+    const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
+    const bool      hinted = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
+    for (long long x0 = 0; x0 < p->xs; x0 += cp) {
+        const long long nx = std::min(cp, p->xs - x0);
+        DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
+                          (hinted && zsrc != p->buf1) ? FFT_HINT_STREAM_IN : 0));
+        if (p->P > 1) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, hinted ? FFT_HINT_STREAM_OUT : 0));
+        else DFFT_TRY(launch_y(p, p->buf1, p->buf1, true, false, x0, nx));
+    }
+    DFFT_TRY(clk.end_stage());
+    DFFT_TRY(clk.end_stage());
+    if (p->P > 1) DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));  // buf2 -> peers' buf1 = [x][ys][N2]
+    DFFT_TRY(clk.end_stage());
+    DFFT_TRY(launch_x(p, p->buf1, p->buf2, true));                      // [x][ys][N2] -> [kx][ys][N2]
+    if (p->P > 1) {
+        DFFT_TRY(comm_exchange(p->comm, p->xd2, p->stream));            // buf2 -> peers' rbuf = [src][xs][yl_src][N2]
+        hipError_t e = launch_pack(p->dtype, -1, p->rbuf, p->buf2, (int)p->xs, (int)n1, (int)n2, (int)p->sy.blk,
+                                   (int)p->sy.size(p->P - 1), p->P, p->stream);
+        if (e != hipSuccess) return fail(DFFT_EHIP, std::string("unpack: ") + hipGetErrorString(e));
+    }
+    DFFT_TRY(clk.end_stage());
+    return DFFT_OK;
+}
+
 static int execute_backward(dfft_plan_s* p, bool sync) {
     const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
     const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
@@ -538,7 +574,7 @@ int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_dev
     tmp.sy = make_slab(n1, total_devices);
     if (tmp.sx.size(total_devices - 1) < 1 || tmp.sy.size(total_devices - 1) < 1)
         return fail(DFFT_EINVAL, "dfft_exchange_layout: last slab would be empty");
-    fill_exchange(&tmp);
+    fill_exchange(&tmp, tmp.xd, direction);
     for (int q = 0; q < total_devices; ++q) {
         if (scount) scount[q] = tmp.xd.scount[q];
         if (soffset) soffset[q] = tmp.xd.soffset[q];
@@ -628,6 +664,10 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         delete p;
         return fail(DFFT_EINVAL, "dfft_plan_create: DFFT_PLAN_INPUT_FROM_IN needs an out-of-place plan");
     }
+    if ((flags & DFFT_PLAN_NATURAL) && (flags & DFFT_PLAN_UNFUSED)) {
+        delete p;
+        return fail(DFFT_EINVAL, "dfft_plan_create: DFFT_PLAN_NATURAL is a fused-pipeline option");
+    }
     {
         // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md); DFFT_CHUNK_MB=0 disables, =k overrides
         long long   mb = 256;
@@ -649,7 +689,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
-    if ((flags & DFFT_PLAN_OVERLAP) && total_devices > 1 && direction == DFFT_FORWARD && !(flags & DFFT_PLAN_UNFUSED)) {
+    if ((flags & DFFT_PLAN_OVERLAP) && total_devices > 1 && direction == DFFT_FORWARD &&
+        !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL))) {
         // parts: DFFT_OVERLAP_PARTS (default 4) per slab, never larger than one Infinity-Cache chunk; derived from the
         // global block size ceil(N0/P) so that every rank cuts identically
         long long   parts = 4;
@@ -672,10 +713,29 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         dfft_plan_destroy(p);
         return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
     }
-    fill_exchange(p);
+    const bool natural = (flags & DFFT_PLAN_NATURAL) != 0;
+    fill_exchange(p, p->xd, natural ? DFFT_FORWARD : direction);
     p->xd.sendbuf = p->buf2;
     p->xd.recvbuf = p->buf1;
-    p->xd.slot = direction == DFFT_FORWARD ? 0 : 1;
+    p->xd.slot = (natural || direction == DFFT_FORWARD) ? 0 : 1;
+    if (natural && total_devices > 1) {
+        // natural-order plans re-slab twice (X->Y for the X pass, Y->X to return to the caller's layout); the second
+        // exchange receives the packed [src][xs][yl_src][N2] blocks into a buffer of its own and uses the other slot
+        e = hipMalloc(&p->rbuf, bytes);
+        if (e != hipSuccess) {
+            dfft_plan_destroy(p);
+            return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+        }
+        fill_exchange(p, p->xd2, DFFT_BACKWARD);
+        p->xd2.sendbuf = p->buf2;
+        p->xd2.recvbuf = p->rbuf;
+        p->xd2.slot = 1;
+        int rc = comm_register(comm, global_idx, 1, p->rbuf, p->device);
+        if (rc) {
+            dfft_plan_destroy(p);
+            return rc;
+        }
+    }
     if (p->part_planes > 0) {
         // overlap mode: parts arrive while later planes are still being transformed in bufferDev1, so the exchange
         // needs a receive buffer of its own (one more slab in HBM; 288 GB makes that a non-issue)
@@ -714,7 +774,9 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_execute: null plan");
     const bool sync = (exec_flags & DFFT_EXEC_SYNC_STAGES) != 0;
     plan->host_timed = sync;
-    int rc = plan->direction == DFFT_FORWARD ? execute_forward(plan, sync) : execute_backward(plan, sync);
+    int rc = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
+             : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
+                                               : execute_backward(plan, sync);
     if (rc) return rc;
     if ((exec_flags & DFFT_EXEC_PRINT) && plan->direction == DFFT_FORWARD) {
         double t[4];
@@ -775,6 +837,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamSynchronize(plan->stream);
     if (plan->stream2) hipStreamSynchronize(plan->stream2);
     if (plan->comm) comm_unregister(plan->comm, plan->me, plan->xd.slot, plan->xd.recvbuf);
+    if (plan->comm && (plan->flags & DFFT_PLAN_NATURAL)) comm_unregister(plan->comm, plan->me, 1, plan->rbuf);
     for (auto& e : plan->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : plan->part_ev)

@@ -48,7 +48,10 @@ extern "C" {
                                        in t3.  Default is fused (pack and transpose folded into the FFT kernels' stores). */
 #define DFFT_PLAN_INPUT_FROM_IN 2u  /* every execute re-reads the caller's `in` (first pass runs out-of-place in -> bufferDev1)
                                        instead of consuming bufferDev1; out-of-place plans only.  Same HBM traffic. */
-#define DFFT_PLAN_OVERLAP 4u        /* P > 1: split the exchange in sub-slabs and overlap t2 with t3 on a second stream */
+#define DFFT_PLAN_OVERLAP 4u        /* forward, P > 1: exchange in X-plane parts on a second stream, overlapped with t0 */
+#define DFFT_PLAN_NATURAL 8u        /* input AND output in the natural X-slab layout [x_local][N1][N2] (both directions):
+                                       the un-transposed output the reference declares (fft_mpi_local_size_3d,
+                                       fft_mpi_3d_api.h:73) but never implements.  Costs a second all-to-all when P > 1. */
 
 /* execute flags */
 #define DFFT_EXEC_ASYNC 0u          /* enqueue on the plan's stream and return */

@@ -227,3 +227,82 @@ def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, monkeypatch):
     outs2, _ = _run_plans(gpu, N, P, "f64", x, +1, api.PLAN_OVERLAP | api.PLAN_INPUT_FROM_IN, inputs)
     for d in range(P):
         assert np.array_equal(outs2[d][:ref[d].size], outs[d][:ref[d].size])
+
+
+def test_in_place_plans_and_reload(gpu):
+    """out == None / out == in selects the in-place mode (bufferDev2 = in, fft_mpi_3d_api.cpp:68-71); input is captured
+    at plan time and can be replaced through bufferDev1 (fftSpeed3d_c2c.cpp:78) for repeated executes."""
+    import torch
+    from distributedfft_amd import api
+    N = (32, 64, 16)
+    x = so.random_input(N, seed=21)
+    ref = so.fftn_reference(x, 1)[0]
+    for out_mode in ("none", "same"):
+        a = torch.from_numpy(x.reshape(-1).copy()).to(gpu)
+        plan = api.Plan(*N, a, None if out_mode == "none" else a, None, 0, 1, api.FORWARD)
+        plan.execute()
+        plan.sync()
+        got = a.cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
+        # a now holds the spectrum; reload a different input through bufferDev1 and execute again
+        x2 = so.random_input(N, seed=22)
+        plan.load_input(torch.from_numpy(x2.reshape(-1)).to(gpu))
+        plan.execute()
+        plan.sync()
+        ref2 = so.fftn_reference(x2, 1)[0]
+        assert np.abs(a.cpu().numpy().reshape(ref2.shape) - ref2).max() / np.abs(ref2).max() < 1e-11
+        plan.destroy()
+        # in-place backward returns N * x2
+        b = a.clone()
+        planb = api.Plan(*N, b, None, None, 0, 1, api.BACKWARD)
+        planb.execute()
+        planb.sync()
+        assert np.abs(b.cpu().numpy().reshape(N) / np.prod(N) - x2).max() < 1e-12
+        planb.destroy()
+
+
+def test_degenerate_and_bad_arguments(gpu, native_lib):
+    import ctypes as C
+    import torch
+    from distributedfft_amd import api
+    x = torch.zeros(64, dtype=torch.complex128, device=gpu)
+    # zero batch is a no-op, not an error
+    assert native_lib.dfft_fft1d_rows(x.data_ptr(), x.data_ptr(), 64, 0, 0, 1, None) == 0
+    assert native_lib.dfft_fft1d_cols(x.data_ptr(), x.data_ptr(), 8, 8, 0, 0, 1, None) == 0
+    # non-positive sizes, bad direction / dtype, missing communicator, wrong communicator size
+    h = C.c_void_p()
+    for args in [(0, 8, 8, 0, 1), (8, -1, 8, 0, 1), (8, 8, 8, 0, 0), (8, 8, 8, 7, 1)]:
+        assert native_lib.dfft_plan_create(C.byref(h), args[0], args[1], args[2], args[3], args[4], x.data_ptr(), None, None, 0, 1, 0) == -1
+    assert native_lib.dfft_plan_create(C.byref(h), 8, 8, 8, 0, 1, x.data_ptr(), None, None, 0, 2, 0) == -1
+    comm = api.Comm.local(4)
+    assert native_lib.dfft_plan_create(C.byref(h), 8, 8, 8, 0, 1, x.data_ptr(), None, comm.handle, 0, 2, 0) == -1
+    comm.destroy()
+    # DFFT_PLAN_INPUT_FROM_IN needs an out-of-place plan
+    big = torch.zeros(512, dtype=torch.complex128, device=gpu)
+    assert native_lib.dfft_plan_create(C.byref(h), 8, 8, 8, 0, 1, big.data_ptr(), None, None, 0, 1, api.PLAN_INPUT_FROM_IN) == -1
+    # buffers smaller than getMaxDataCount are rejected by the host mirror before reaching the library
+    with pytest.raises(ValueError):
+        api.Plan(8, 8, 8, x, None, None, 0, 1, api.FORWARD)
+
+
+@pytest.mark.parametrize("N,P", [((32, 24, 16), 1), ((64, 64, 64), 4), ((25, 10, 16), 4), ((24, 10, 12), 4), ((128, 96, 64), 2)])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_natural_order_plans_vs_fftn(gpu, N, P, prec):
+    """DFFT_PLAN_NATURAL: X-slabbed natural layout in and out, both directions: forward equals numpy.fftn
+    of the whole array cut into X slabs; backward of that returns N * input."""
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=5 + n0)
+    F = np.fft.fftn(x)
+    cut = lambda a: [a[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    outs, _ = _run_plans(gpu, N, P, prec, None, +1, api.PLAN_NATURAL, cut(x))
+    scale = np.abs(F).max()
+    got = []
+    for g, ref in enumerate(cut(F)):
+        o = outs[g][:ref.size].reshape(ref.shape)
+        assert np.abs(o - ref).max() / scale < TOL[prec], f"natural forward N={N} P={P} dev={g}"
+        got.append(ref)
+    backs, _ = _run_plans(gpu, N, P, prec, None, -1, api.PLAN_NATURAL | api.PLAN_INPUT_FROM_IN, got)
+    for g, ref in enumerate(cut(x)):
+        b = backs[g][:ref.size].reshape(ref.shape) / float(n0 * n1 * n2)
+        assert np.abs(b - ref).max() < TOL[prec] * 10, f"natural backward N={N} P={P} dev={g}"
