@@ -491,7 +491,9 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
-        constexpr bool can_stage = P::S > 1 && (size_t)(P::N + 1) * CBC * GC * sizeof(V) <= 80 * 1024;
+        // staging pays when the tile rows are full 128-byte lines and the [CB][N+1] image fits the LDS
+        // (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; tools/kbench5.hip)
+        constexpr bool can_stage = P::S > 1 && CBC * (int)sizeof(V) >= 128 && (size_t)(P::N + 1) * CBC * GC * sizeof(V) <= 144 * 1024;
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);

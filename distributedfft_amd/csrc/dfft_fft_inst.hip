@@ -15,16 +15,20 @@ template <int N> struct PlanFor;
 DFFT_PLAN_TABLE(DFFT_DECL_PLAN)
 #undef DFFT_DECL_PLAN
 
+// fp32 uses the table's plan unless a length is listed here (measured: 16 points/thread helps 1024-point fp64 columns,
+// 3.4 -> 4.4 TB/s, but costs fp32 -- 16-column tiles then need 1024-thread blocks: 1024^3 fp32 7.4 -> 12.4 ms in t0).
+template <int N> struct PlanFor32 : PlanFor<N> {};
+template <> struct PlanFor32<1024> { using type = Plan<1024, 8, 8, 8, 8, 2>; };
+
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
-    using P = typename PlanFor<N>::type;
-    if (L.dtype == F64) return launch_plan<double2, P>(L, stream);
-    if (L.dtype == F32) return launch_plan<float2, P>(L, stream);
+    if (L.dtype == F64) return launch_plan<double2, typename PlanFor<N>::type>(L, stream);
+    if (L.dtype == F32) return launch_plan<float2, typename PlanFor32<N>::type>(L, stream);
     return hipErrorInvalidValue;
 }
 
 template <int N> int cols_n(int dtype) {
-    using P = typename PlanFor<N>::type;
-    return dtype == F64 ? cols_per_tile<double2, P>() : cols_per_tile<float2, P>();
+    return dtype == F64 ? cols_per_tile<double2, typename PlanFor<N>::type>()
+                        : cols_per_tile<float2, typename PlanFor32<N>::type>();
 }
 #define DFFT_INST_PLAN(N, GRP, E, ...) DFFT_INST_IF_##GRP(N)
 #define DFFT_DO_INST(N)                                                       \

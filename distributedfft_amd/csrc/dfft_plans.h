@@ -31,7 +31,7 @@
     X(384, 3, 24, 8, 8, 3, 2)     \
     X(512, 3, 8, 8, 8, 8)         \
     X(768, 4, 24, 8, 8, 4, 3)     \
-    X(1024, 5, 8, 8, 8, 8, 2)     \
+    X(1024, 5, 16, 8, 8, 8, 2)    \
     X(2048, 6, 16, 8, 8, 8, 4)
 
 #define DFFT_NUM_INST_GROUPS 7

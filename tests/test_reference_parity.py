@@ -34,7 +34,7 @@ def _summary(stdout):
     return out
 
 
-@pytest.mark.parametrize("N", [(64, 64, 64), (128, 64, 32)])
+@pytest.mark.parametrize("N", [(64, 64, 64), (128, 64, 32), (256, 256, 256)])  # the last one is BASELINE config 2
 def test_forward_output_matches_reference_gpu_code(gpu, tmp_path, N):
     """3dmpifft_opt + templateFFT (the reference's GPU implementation) on the driver's own input, P = 1, vs our library
     and vs the oracle -- identical X x Y x Z input, <= 1e-11 relative to max|ref| (north star)."""
