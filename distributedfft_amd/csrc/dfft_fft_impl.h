@@ -441,7 +441,7 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, KG::THREADS, KG::LDS_BYTES);
         if (e != hipSuccess) {
             // advisory only (the grid-stride loop is correct for any grid): fall back to the LDS / wave-slot bound
-            launch_debug(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor", (int)KG::LDS_BYTES, KG::THREADS);
+            (void)launch_debug(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor", (int)KG::LDS_BYTES, KG::THREADS);
             (void)hipGetLastError();
             const int waves = (KG::THREADS + 63) / 64;
             occ = 32 / waves;

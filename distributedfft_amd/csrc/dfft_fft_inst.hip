@@ -18,6 +18,7 @@ DFFT_PLAN_TABLE(DFFT_DECL_PLAN)
 // fp32 uses the table's plan unless a length is listed here (measured: 16 points/thread helps 1024-point fp64 columns,
 // 3.4 -> 4.4 TB/s, but costs fp32 -- 16-column tiles then need 1024-thread blocks: 1024^3 fp32 7.4 -> 12.4 ms in t0).
 template <int N> struct PlanFor32 : PlanFor<N> {};
+// (512-point fp32 with 16 points per thread was also tried: X pass 0.567 -> 0.524 ms but the Z+Y stage 0.70 -> 1.00 ms.)
 template <> struct PlanFor32<1024> { using type = Plan<1024, 8, 8, 8, 8, 2>; };
 
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {

@@ -9,6 +9,7 @@
 #ifndef __FFT_MPI_3D_API_H__
 #define __FFT_MPI_3D_API_H__
 
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -145,16 +146,30 @@ inline fft_mpi_3d_plan_p fft_mpi_plan_dft_c2c_3d(longInt64 n0, longInt64 n1, lon
     dfft_comm_t c = nullptr;
     if (totalDevCount > 1) {
         State& s = state();
-        std::lock_guard<std::mutex> lk(s.m);
-        if (s.local) {
-            c = s.local;
-        } else {
-            if (!s.have_id || devIdx >= (int)s.rccl.size()) {
-                fprintf(stderr, "[%s:%d] fft_mpi_init must run before plan creation\n", __FILE__, __LINE__);
-                exit(EXIT_FAILURE);
+        bool   create = false;
+        char   id[128];
+        {
+            std::lock_guard<std::mutex> lk(s.m);
+            if (s.local) {
+                c = s.local;
+            } else {
+                if (!s.have_id || devIdx >= (int)s.rccl.size()) {
+                    fprintf(stderr, "[%s:%d] fft_mpi_init must run before plan creation\n", __FILE__, __LINE__);
+                    exit(EXIT_FAILURE);
+                }
+                c = s.rccl[devIdx];
+                if (!c) {
+                    create = true;
+                    memcpy(id, s.rccl_id, sizeof(id));
+                }
             }
-            if (!s.rccl[devIdx]) DFFT_CHECK(dfft_comm_create_rccl(s.rccl_id, totalDevCount, plan->globalDevIdx, &s.rccl[devIdx]));
-            c = s.rccl[devIdx];
+        }
+        if (create) {
+            // collective over every device of every rank: must not be called under the lock (the other device
+            // threads of this process have to get in here too); slot devIdx belongs to this device thread alone
+            DFFT_CHECK(dfft_comm_create_rccl(id, totalDevCount, plan->globalDevIdx, &c));
+            std::lock_guard<std::mutex> lk(s.m);
+            s.rccl[devIdx] = c;
         }
     }
     DFFT_CHECK(dfft_plan_create(&plan->handle, n0, n1, n2, DFFT_F64, direction, in, out, c, plan->globalDevIdx,
