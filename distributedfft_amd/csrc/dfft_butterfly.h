@@ -91,6 +91,34 @@ template <int DIR, class V> struct Butterfly<5, DIR, V> {
     }
 };
 
+template <int DIR, class V> struct Butterfly<7, DIR, V> {
+    static __device__ __forceinline__ void run(V* u) {
+        using Rt = typename real_of<V>::type;
+        // c_m = cos(2 pi m / 7), s_m = sin(2 pi m / 7)
+        const Rt c1 = Rt(0.62348980185873353052500488400424), c2 = Rt(-0.22252093395631440428890256449679),
+                 c3 = Rt(-0.90096886790241912623610231950745);
+        const Rt s1 = Rt(0.78183148246802980870844452667406), s2 = Rt(0.97492791218182360701813168299393),
+                 s3 = Rt(0.43388373911755812047576833284836);
+        const V t1 = cadd(u[1], u[6]), t2 = cadd(u[2], u[5]), t3 = cadd(u[3], u[4]);
+        const V d1 = csub(u[1], u[6]), d2 = csub(u[2], u[5]), d3 = csub(u[3], u[4]);
+        const V a0 = u[0];
+        // m_j = a0 + sum_k cos(2 pi j k / 7) t_k,  n_j = sum_k sin(2 pi j k / 7) d_k   (j k mod 7 folded to 1..3)
+        const V m1 = V{a0.x + c1 * t1.x + c2 * t2.x + c3 * t3.x, a0.y + c1 * t1.y + c2 * t2.y + c3 * t3.y};
+        const V m2 = V{a0.x + c2 * t1.x + c3 * t2.x + c1 * t3.x, a0.y + c2 * t1.y + c3 * t2.y + c1 * t3.y};
+        const V m3 = V{a0.x + c3 * t1.x + c1 * t2.x + c2 * t3.x, a0.y + c3 * t1.y + c1 * t2.y + c2 * t3.y};
+        const V n1 = mul_mi<DIR>(V{s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y});
+        const V n2 = mul_mi<DIR>(V{s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y});
+        const V n3 = mul_mi<DIR>(V{s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y});
+        u[0] = V{a0.x + t1.x + t2.x + t3.x, a0.y + t1.y + t2.y + t3.y};
+        u[1] = cadd(m1, n1);
+        u[6] = csub(m1, n1);
+        u[2] = cadd(m2, n2);
+        u[5] = csub(m2, n2);
+        u[3] = cadd(m3, n3);
+        u[4] = csub(m3, n3);
+    }
+};
+
 template <int DIR, class V> struct Butterfly<8, DIR, V> {
     static __device__ __forceinline__ void run(V* u) {
         using Rt = typename real_of<V>::type;

@@ -12,15 +12,18 @@
     X(4, 0, 4, 4)                 \
     X(5, 0, 5, 5)                 \
     X(6, 0, 6, 3, 2)              \
+    X(7, 0, 7, 7)                 \
     X(8, 0, 8, 8)                 \
     X(9, 0, 3, 3, 3)              \
     X(10, 0, 10, 5, 2)            \
     X(12, 0, 12, 4, 3)            \
+    X(14, 0, 14, 7, 2)            \
     X(16, 0, 4, 4, 4)             \
     X(24, 0, 24, 8, 3)            \
     X(25, 0, 5, 5, 5)             \
     X(32, 1, 8, 8, 4)             \
     X(48, 1, 24, 8, 3, 2)         \
+    X(49, 1, 7, 7, 7)             \
     X(64, 1, 8, 8, 8)             \
     X(96, 1, 24, 8, 4, 3)         \
     X(100, 1, 20, 5, 5, 4)        \
@@ -28,6 +31,7 @@
     X(128, 2, 8, 8, 8, 2)         \
     X(192, 2, 24, 8, 8, 3)        \
     X(256, 2, 8, 8, 8, 4)         \
+    X(343, 2, 7, 7, 7, 7)         \
     X(384, 3, 24, 8, 8, 3, 2)     \
     X(512, 3, 8, 8, 8, 8)         \
     X(768, 4, 24, 8, 8, 4, 3)     \

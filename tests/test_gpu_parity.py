@@ -13,7 +13,8 @@ from oracle import slab_oracle as so
 pytestmark = pytest.mark.gpu
 
 TOL = {"f64": 1e-11, "f32": 5e-4}
-LENGTHS = [2, 3, 4, 5, 6, 8, 9, 10, 12, 16, 24, 25, 32, 48, 64, 96, 100, 125, 128, 192, 256, 384, 512, 768, 1024, 2048]
+LENGTHS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 25, 32, 48, 49, 64, 96, 100, 125, 128, 192, 256, 343, 384, 512, 768, 1024,
+           2048]
 
 
 def _torch_dtype(name):
@@ -110,7 +111,9 @@ SHAPES = [
     ((10, 10, 8), 4),     # uneven in X and Y: xl=3 (last 1), yl=3 (last 1)
     ((25, 10, 16), 4),    # uneven X (7,7,7,4) and Y (3,3,3,1)
     ((24, 10, 12), 4),    # ragged N2 (12 % 8 != 0, 12 % 16 != 0) with uneven Y (3,3,3,1)
-    ((96, 100, 20), 2) if False else ((48, 100, 12), 2),  # radix-5 Y axis, ragged Z
+    ((48, 100, 12), 2),   # radix-5 Y axis, ragged Z
+    ((14, 49, 16), 2),    # radix-7 X and Y axes
+    ((343, 8, 8), 1),     # 7*7*7 X axis
 ]
 
 
@@ -203,9 +206,9 @@ def test_rccl_single_rank_communicator(gpu):
 def test_unsupported_length_fails_loudly(gpu):
     import torch
     from distributedfft_amd import api
-    a = torch.zeros(7 * 8 * 8, dtype=torch.complex128, device=gpu)
+    a = torch.zeros(11 * 8 * 8, dtype=torch.complex128, device=gpu)
     with pytest.raises(api.DfftError):
-        api.Plan(7, 8, 8, a, torch.zeros_like(a), None, 0, 1, api.FORWARD)
+        api.Plan(11, 8, 8, a, torch.zeros_like(a), None, 0, 1, api.FORWARD)
 
 
 @pytest.mark.parametrize("N,P,parts", [((64, 64, 64), 4, 4), ((64, 48, 24), 2, 3), ((25, 10, 16), 4, 2), ((128, 128, 32), 8, 4),

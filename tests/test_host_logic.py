@@ -98,7 +98,7 @@ def test_bad_arguments_return_codes(native_lib):
     # last Y slab empty: N1 = 9 over 4 devices -> 3,3,3,0 (the reference cannot run this either)
     assert native_lib.dfft_exchange_layout(16, 9, 8, 4, 0, 1, None, None, None, None) != 0
     assert b"last slab" in native_lib.dfft_last_error()
-    for n, ok in [(512, 1), (768, 1), (1024, 1), (2048, 1), (256, 1), (7, 0), (11, 0), (4096, 0), (0, 0), (-4, 0)]:
+    for n, ok in [(512, 1), (768, 1), (1024, 1), (2048, 1), (256, 1), (7, 1), (343, 1), (11, 0), (13, 0), (4096, 0), (0, 0), (-4, 0)]:
         assert native_lib.dfft_length_supported(n) == ok
 
 
