@@ -129,3 +129,57 @@ def test_bench_control_plane_dry_run(native_lib, world):
         assert p.returncode == 0, e[-2000:]
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["ok"] and d["n_gpus"] == world and d["elements_exchanged"] == 512 ** 3 and d["local_count"] == 512 ** 3 // world
+
+
+STUB_WORKER = r'''
+import os, sys, runpy, json
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+import torch
+from distributedfft_amd import api
+
+# Replace the native plan / communicator objects by stubs: NOTHING is computed; this only drives bench.py's multi-rank
+# control flow and report assembly (the part that cannot be exercised on a single-GPU box).
+class StubPlan:
+    def __init__(self, n0, n1, n2, a, b, comm, rank, P, direction, flags=0):
+        self.a, self.b, self.direction, self.flags = a, b, direction, flags
+    def execute(self, flags=0):
+        n = min(self.a.numel(), self.b.numel())
+        self.b[:n] = self.a[:n] * (1.0 if self.direction > 0 else 4096.0)   # "backward(forward(x)) = N x" for 16^3
+    def sync(self): pass
+    def stage_times(self): return [1e-3, 0.0, (5e-4 if self.flags & api.PLAN_OVERLAP else 2e-3), 1e-3]
+    def kernel_times(self): raise api.DfftError(-1, "stub", "interleaved")
+    def destroy(self): pass
+class StubComm:
+    def destroy(self): pass
+api._BENCH_STUB = True
+api.Plan = StubPlan
+api.Comm.rccl_unique_id = staticmethod(lambda: bytes(range(128)))
+api.Comm.rccl = staticmethod(lambda uid, P, r: StubComm())
+sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--size", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+runpy.run_path(os.path.join(os.environ["DFFT_ROOT"], "bench.py"), run_name="__main__")
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multirank_report_with_stubbed_plans(native_lib, world):
+    """Every Python statement of bench.py's P > 1 branch (gloo rendezvous, id broadcast, timing reduction, overlap and
+    serial diagnostics, JSON assembly) with the native objects stubbed out -- the RCCL data path itself needs >= 2 GPUs."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DFFT_ROOT=str(ROOT))
+        procs.append(subprocess.Popen([sys.executable, "-c", STUB_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["unit"] == "GFlops/s" and d["value"] > 0
+    assert d["stages_ms"]["t2"] == 0.5 and d["stages_ms_without_overlap"]["t2"] == 2.0
+    assert d["overlap_result_bit_identical"] is True and d["xgmi"]["t2_full_ms"] == 2.0
+    assert d["roofline"]["kernel"].startswith("fft_cols X") and d["roundtrip_abs_error"] < 1e-12
+    assert ("cpu_baseline" not in d) and d["vs_baseline"] is None
+    for o, _ in outs[1:]:
+        assert not [l for l in o.splitlines() if l.startswith("{")]  # only rank 0 prints
