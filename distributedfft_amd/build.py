@@ -107,6 +107,12 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
         _run([HIPCC] + COMMON + ["-x", "hip", "-I" + str(INCLUDE / "dfft_mpi_shim"), str(drv_src), "-x", "none",
                                  "-o", str(drv), "-L" + str(LIBDIR), "-ldfft_mi355x", "-lpthread",
                                  "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
+    # heFFTe-protocol benchmark front-end on top of the C-ABI (same CLI/report as the CPU baseline's speed3d_c2c)
+    s3d = LIBDIR / "speed3d_c2c"
+    s3d_src = CSRC / "speed3d_c2c_dfft.cpp"
+    if force or _newer(s3d, [s3d_src, lib] + hdrs):
+        _run([HIPCC] + COMMON + ["-x", "hip", str(s3d_src), "-x", "none", "-o", str(s3d), "-L" + str(LIBDIR),
+                                 "-ldfft_mi355x", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
     return lib
 
 

@@ -858,6 +858,14 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
     return fft_rows(in, out, (int)n, batch, dtype, direction, (hipStream_t)stream);
 }
 
+int dfft_scale(void* data, long long count, int dtype, double s, void* stream) {
+    if (!data || count < 0 || (dtype != DFFT_F64 && dtype != DFFT_F32)) return fail(DFFT_EINVAL, "dfft_scale: bad arguments");
+    if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_scale: no HIP device visible (no CPU fallback)");
+    hipError_t e = launch_scale(dtype, data, count, s, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(DFFT_EHIP, std::string("dfft_scale: ") + hipGetErrorString(e));
+    return DFFT_OK;
+}
+
 int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
                     void* stream) {
     if (!in || !out || batch < 0 || width < 1) return fail(DFFT_EINVAL, "dfft_fft1d_cols: bad arguments");

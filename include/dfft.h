@@ -135,6 +135,10 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
 int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
                     void* stream);
 
+/* data[i] *= s for `count` complex elements on the device (the 1/N normalisation both transforms leave to the caller;
+ * the reference's scale_element kernel, kernel_func.cpp:102-157, used only by 3dmpifft_roc). */
+int dfft_scale(void* data, long long count, int dtype, double s, void* stream);
+
 /* ---- tiny TCP rendezvous for multi-process launches without MPI ----------------------------------------------------------
  * Replaces what the reference driver needs from MPI besides moving data (MPI_Comm_rank/size, MPI_Bcast of the RCCL id,
  * MPI_Barrier, MPI_Reduce(MAX), fftSpeed3d_c2c.cpp:18-26,120-124).  Rank/size/address come from the environment:

@@ -108,3 +108,21 @@ def test_speedtest_sh_cli(gpu, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     s = _summary(r.stdout)
     assert s["size"] == "32x32x32" and float(s["err"]) < 1e-11
+
+
+@pytest.mark.parametrize("precision,tol", [("double", 1e-11), ("float", 5e-4)])
+def test_heffte_protocol_front_end(gpu, tmp_path, precision, tol):
+    """speed3d_c2c <backend> <precision> X Y Z: the heFFTe benchmark protocol (seed-4242 input, forward with 1/N scaling +
+    backward, tolerance check, report block of speed3d.h:159-183) on the MI355X path -- the harness that times the CPU
+    baseline, pointed at our library."""
+    from distributedfft_amd import _lib
+    exe = _lib.LIB_PATH.parent / "speed3d_c2c"
+    assert exe.exists()
+    r = _run([exe, "stock", precision, 64, 32, 16, "-slabs", "-p2p_pl"], cwd=tmp_path)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    out = r.stdout
+    assert "heFFTe performance test" in out and "Size:      64x32x16" in out
+    err = float(re.search(r"Max error:\s*([0-9.eE+-]+)", out).group(1))
+    assert err < tol and float(re.search(r"Tolerance:\s*([0-9.eE+-]+)", out).group(1)) == tol
+    assert float(re.search(r"Performance:\s*([0-9.eE+-]+)", out).group(1)) > 0
+    assert float(re.search(r"Time per run:\s*([0-9.eE+-]+)", out).group(1)) > 0
