@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -142,14 +143,19 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
 int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
     const size_t         eb = elem_bytes(x.dtype);
     const ncclDataType_t ty = x.dtype == DFFT_F64 ? ncclDouble : ncclFloat;
-    // self chunk: plain device copy (no link involved)
-    if (r.sc[x.me] > 0)
+    // self chunk: plain device copy (no link involved).  DFFT_RCCL_SELF_SENDRECV=1 sends it through ncclSend/ncclRecv
+    // instead, so that the grouped send/recv code below can be exercised with a single GPU (tests).
+    static const bool self_via_rccl = [] {
+        const char* e = std::getenv("DFFT_RCCL_SELF_SENDRECV");
+        return e && *e && *e != '0';
+    }();
+    if (r.sc[x.me] > 0 && !self_via_rccl)
         DFFT_HIP_TRY(hipMemcpyAsync((char*)x.recvbuf + (size_t)r.ro[x.me] * eb, (const char*)x.sendbuf + (size_t)r.so[x.me] * eb,
                                     (size_t)r.sc[x.me] * eb, hipMemcpyDeviceToDevice, stream));
-    if (x.P == 1) return DFFT_OK;
+    if (x.P == 1 && !self_via_rccl) return DFFT_OK;
     ncclResult_t rc = ncclGroupStart();
     if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(rc));
-    for (int i = 1; i < x.P; ++i) {
+    for (int i = self_via_rccl ? 0 : 1; i < x.P; ++i) {
         const int to = (x.me + i) % x.P, from = (x.me - i + x.P) % x.P;
         if (r.sc[to] > 0) {
             rc = ncclSend((const char*)x.sendbuf + (size_t)r.so[to] * eb, (size_t)r.sc[to] * 2, ty, to, c->nccl, stream);

@@ -139,6 +139,7 @@ struct dfft_plan_s {
     int         P, me;
     unsigned    flags;
     bool        inplace, is_last;
+    bool        exch = false;  // t2 runs: P > 1, or DFFT_FORCE_EXCHANGE=1 with an RCCL communicator (single-GPU tests)
     long long   max_count;
     Slab        sx, sy;       // X slabs (before), Y slabs (after)
     long long   xs, ys;       // this device's extents
@@ -335,7 +336,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // The Z and Y passes run chunk by chunk over groups of planes that fit the 256 MiB Infinity Cache, so the Y pass
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
-    const bool      y_packs = fused && p->P > 1;
+    const bool      y_packs = fused && p->exch;
     if (y_packs && (p->flags & DFFT_PLAN_OVERLAP) && p->part_planes > 0) {
         // ---- t0 pipelined against t2: the exchange of plane part k (stream2) runs while the Z+Y passes of part k+1
         // (stream) compute.  Any X-plane sub-range of the packed send layout is contiguous on both sides, so the parts
@@ -395,7 +396,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     }
     // ---- t2: exchange ----
     const void* xsrc = p->buf1;
-    if (p->P > 1) {
+    if (p->exch) {
         DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));
     } else if (!fused) {
         // reference structure: full-size self copy bufferDev2 -> bufferDev1 (fft_mpi_3d_api.cpp:613-630)
@@ -429,15 +430,15 @@ static int execute_natural(dfft_plan_s* p, bool sync) {
         const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                           (hinted && zsrc != p->buf1) ? FFT_HINT_STREAM_IN : 0));
-        if (p->P > 1) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, hinted ? FFT_HINT_STREAM_OUT : 0));
+        if (p->exch) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, hinted ? FFT_HINT_STREAM_OUT : 0));
         else DFFT_TRY(launch_y(p, p->buf1, p->buf1, true, false, x0, nx));
     }
     DFFT_TRY(clk.end_stage());
     DFFT_TRY(clk.end_stage());
-    if (p->P > 1) DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));  // buf2 -> peers' buf1 = [x][ys][N2]
+    if (p->exch) DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));  // buf2 -> peers' buf1 = [x][ys][N2]
     DFFT_TRY(clk.end_stage());
     DFFT_TRY(launch_x(p, p->buf1, p->buf2, true));                      // [x][ys][N2] -> [kx][ys][N2]
-    if (p->P > 1) {
+    if (p->exch) {
         DFFT_TRY(comm_exchange(p->comm, p->xd2, p->stream));            // buf2 -> peers' rbuf = [src][xs][yl_src][N2]
         hipError_t e = launch_pack(p->dtype, -1, p->rbuf, p->buf2, (int)p->xs, (int)n1, (int)n2, (int)p->sy.blk,
                                    (int)p->sy.size(p->P - 1), p->P, p->stream);
@@ -464,7 +465,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     DFFT_TRY(clk.end_stage());
     // ---- exchange back ----
     void* ybuf = p->buf2;  // where the Y/Z passes run
-    if (p->P > 1) {
+    if (p->exch) {
         DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));  // buf2 -> peers' buf1 (packed [d][xs][yl_d][N2])
     } else if (!fused) {
         DFFT_HIP_TRY(hipMemcpyAsync(p->buf1, p->buf2, (size_t)p->xs * n1 * n2 * elem_bytes(p->dtype),
@@ -480,7 +481,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("unpack: ") + hipGetErrorString(e));
         DFFT_TRY(clk.end_stage());
     }
-    const bool      y_unpacks = fused && p->P > 1;
+    const bool      y_unpacks = fused && p->exch;
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
@@ -640,6 +641,10 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     p->me = global_idx;
     p->flags = flags;
     p->is_last = (global_idx == total_devices - 1);
+    {
+        const char* fe = getenv("DFFT_FORCE_EXCHANGE");
+        p->exch = total_devices > 1 || (comm && comm_kind(comm) == 1 && fe && *fe && *fe != '0');
+    }
     p->sx = make_slab(n0, total_devices);
     p->sy = make_slab(n1, total_devices);
     p->xs = p->sx.size(global_idx);
@@ -689,7 +694,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
-    if ((flags & DFFT_PLAN_OVERLAP) && total_devices > 1 && direction == DFFT_FORWARD &&
+    if ((flags & DFFT_PLAN_OVERLAP) && p->exch && direction == DFFT_FORWARD &&
         !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL))) {
         // parts: DFFT_OVERLAP_PARTS (default 4) per slab, never larger than one Infinity-Cache chunk; derived from the
         // global block size ceil(N0/P) so that every rank cuts identically
@@ -718,7 +723,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     p->xd.sendbuf = p->buf2;
     p->xd.recvbuf = p->buf1;
     p->xd.slot = (natural || direction == DFFT_FORWARD) ? 0 : 1;
-    if (natural && total_devices > 1) {
+    if (natural && p->exch) {
         // natural-order plans re-slab twice (X->Y for the X pass, Y->X to return to the caller's layout); the second
         // exchange receives the packed [src][xs][yl_src][N2] blocks into a buffer of its own and uses the other slot
         e = hipMalloc(&p->rbuf, bytes);

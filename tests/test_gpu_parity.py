@@ -3,6 +3,7 @@
 Tolerance: the north star asks for <= 1e-11 max error in fp64 (heFFTe's bar, test_common.h:136-140); it is applied to
 the forward result relative to max|reference| ("parity metric").  fp32: 5e-4 (same heFFTe table).
 """
+import os
 import threading
 
 import numpy as np
@@ -309,3 +310,56 @@ def test_natural_order_plans_vs_fftn(gpu, N, P, prec):
     for g, ref in enumerate(cut(x)):
         b = backs[g][:ref.size].reshape(ref.shape) / float(n0 * n1 * n2)
         assert np.abs(b - ref).max() < TOL[prec] * 10, f"natural backward N={N} P={P} dev={g}"
+
+
+_RCCL_SELF_SCRIPT = r"""
+import numpy as np, torch
+from distributedfft_amd import api
+N = (64, 48, 32)
+rng = np.random.default_rng(5)
+x = (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+ref = np.fft.fftn(x)
+dev = torch.device("cuda:0")
+comm = api.Comm.rccl(api.Comm.rccl_unique_id(), 1, 0)
+def run(data, direction, flags):
+    a = torch.from_numpy(np.ascontiguousarray(data).reshape(-1)).to(dev)
+    b = torch.zeros_like(a)
+    torch.cuda.synchronize()
+    p = api.Plan(*N, a, b, comm, 0, 1, direction, flags)
+    for _ in range(2):
+        p.execute()
+    p.sync()
+    t = p.stage_times()
+    out = b.cpu().numpy()
+    p.destroy()
+    return out, t
+scale = np.abs(ref).max()
+tr = ref.transpose(1, 2, 0)                      # [y][z][kx], the pipeline's output layout
+for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP, api.PLAN_INPUT_FROM_IN | api.PLAN_UNFUSED):
+    out, t = run(x, api.FORWARD, flags)
+    assert np.abs(out.reshape(tr.shape) - tr).max() / scale < 1e-11, flags
+    assert t[2] > 0 or flags & api.PLAN_OVERLAP, (flags, t)   # the exchange stage really ran
+out, _ = run(tr, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+assert np.abs(out.reshape(N) / x.size - x).max() < 1e-11
+out, _ = run(x, api.FORWARD, api.PLAN_INPUT_FROM_IN | api.PLAN_NATURAL)
+assert np.abs(out.reshape(N) - ref).max() / scale < 1e-11
+out, _ = run(ref, api.BACKWARD, api.PLAN_INPUT_FROM_IN | api.PLAN_NATURAL)
+assert np.abs(out.reshape(N) / x.size - x).max() < 1e-11
+comm.destroy()
+print("RCCL-SELF-OK")
+"""
+
+
+def test_rccl_grouped_send_recv_on_one_gpu(gpu, tmp_path):
+    """The only RCCL traffic one GPU allows: a world-size-1 communicator whose self chunk goes through the grouped
+    ncclSend/ncclRecv code of exchange_rccl (DFFT_RCCL_SELF_SENDRECV=1) with the exchange stage forced on at P = 1
+    (DFFT_FORCE_EXCHANGE=1) -- forward (serial, overlapped parts on the second stream, unfused), backward and both
+    natural-order directions.  Separate process: both switches are read once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFFT_RCCL_SELF_SENDRECV="1", DFFT_FORCE_EXCHANGE="1", DFFT_OVERLAP_PARTS="4",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SELF_SCRIPT], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0 and "RCCL-SELF-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
