@@ -5,7 +5,9 @@
 // Everything here is static C++ for gfx950; there is no string code generator and no hiprtc.
 //
 // Conventions
-//   V    = double2 (fp64 path) or float2 (fp32 path): one complex number, .x = re, .y = im.
+//   V    = double2 (fp64 path) or float2 (fp32 path): one complex number, .x = re, .y = im; or cpair: the same element
+//          of TWO adjacent fp32 columns, component-major (.x = both real parts, .y = both imaginary parts), so that every
+//          butterfly line below compiles to packed-fp32 VALU instructions (v_pk_add/mul/fma_f32) and one lane moves 16 B.
 //   DIR  = +1 forward  (kernel e^{-i theta}, reference FORWARD,  fft_mpi_common.h:18)
 //        = -1 backward (kernel e^{+i theta}, reference BACKWARD, fft_mpi_common.h:19), unnormalised.
 //   butterfly<R, DIR>(u): u[0..R-1] in, natural-order DFT of length R out (u[k] = sum_n u[n] w^{nk}).
@@ -14,15 +16,23 @@
 
 namespace dfft {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct alignas(16) cpair {
+    f32x2 x, y;
+};
+
 template <class V> struct real_of;
 template <> struct real_of<double2> { using type = double; };
 template <> struct real_of<float2>  { using type = float; };
+template <> struct real_of<cpair>   { using type = float; };
 
 template <class V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
 template <class V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
-template <class V> __device__ __forceinline__ V cmul(V a, V b) {
+// data * twiddle: A is the data type (V), B a scalar complex (the twiddle type; for cpair both columns share it)
+template <class A, class B> __device__ __forceinline__ A cmul(A a, B b) {
     // (a.x + i a.y)(b.x + i b.y); the compiler contracts these into fma chains.
-    return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+    return A{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
 // multiply by e^{-i DIR pi/2}: forward -> times (-i), backward -> times (+i)
 template <int DIR, class V> __device__ __forceinline__ V mul_mi(V a) {

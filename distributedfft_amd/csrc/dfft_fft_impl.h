@@ -82,6 +82,26 @@ struct TuneColsStreamOut : TuneCols {
     static constexpr bool NTS = true;
 };
 
+// Per data type V: W = scalar complex of the twiddles, G = what one lane moves to/from HBM (one V), LANES = columns per V.
+template <class V> struct VecTraits {
+    using W = V;
+    using G = V;
+    static constexpr int LANES = 1;
+    static __device__ __forceinline__ V from_g(G g) { return g; }
+    static __device__ __forceinline__ G to_g(V v) { return v; }
+    static __device__ __forceinline__ V zero() { return V{0, 0}; }
+    static __device__ __forceinline__ W lane(V v, int) { return v; }
+};
+template <> struct VecTraits<cpair> {
+    using W = float2;
+    using G = f32x4;  // (re0, im0, re1, im1): two adjacent columns as they lie in memory
+    static constexpr int LANES = 2;
+    static __device__ __forceinline__ cpair from_g(G g) { return cpair{f32x2{g.x, g.z}, f32x2{g.y, g.w}}; }
+    static __device__ __forceinline__ G to_g(cpair v) { return G{v.x.x, v.y.x, v.x.y, v.y.y}; }
+    static __device__ __forceinline__ cpair zero() { return cpair{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}; }
+    static __device__ __forceinline__ W lane(cpair v, int l) { return l == 0 ? W{v.x.x, v.y.x} : W{v.x.y, v.y.y}; }
+};
+
 // number of stored twiddle powers per butterfly
 constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 5 ? 3 : (R >= 3 ? 2 : (R >= 2 ? 1 : 0))); }
 
@@ -127,8 +147,8 @@ template <bool WAVE_LOCAL> __device__ __forceinline__ void group_sync() {
 }
 
 // stored slot s of a butterfly holds w^{1 << s} when TWPOW, else w^{s+1}
-template <class V, class P, int S, int DIR, bool TWPOW>
-__device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, int j) {
+template <class W, class P, int S, int DIR, bool TWPOW>
+__device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, int j) {
     if constexpr (S < P::S) {
         using SI = StageInfo<P, S, TWPOW>;
         if constexpr (S > 0) {
@@ -138,13 +158,13 @@ __device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, 
 #pragma unroll
                 for (int s = 0; s < SI::SLOTS; ++s) {
                     const int r = TWPOW ? (1 << s) : (s + 1);
-                    V w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
+                    W w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
                     if (DIR < 0) w.y = -w.y;
                     twr[SI::TWOFF + q * SI::SLOTS + s] = w;
                 }
             }
         }
-        load_twiddles<V, P, S + 1, DIR, TWPOW>(twr, tw, j);
+        load_twiddles<W, P, S + 1, DIR, TWPOW>(twr, tw, j);
     }
 }
 
@@ -155,8 +175,9 @@ __device__ __forceinline__ void load_twiddles(V* twr, const V* __restrict__ tw, 
 enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 
 template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW>
-__device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, int c) {
+__device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W* twr, V* lds, int j, int c) {
     using SI = StageInfo<P, S, TWPOW>;
+    using W = typename VecTraits<V>::W;
     constexpr int R = SI::R, B = SI::B, NS = SI::NS, T = P::T, E = P::E;
 #pragma unroll
     for (int q = 0; q < B; ++q) {
@@ -172,13 +193,13 @@ __device__ __forceinline__ void run_stages(V* v, const V* twr, V* lds, int j, in
                 const int m = ((j + q * T) % NS) * (P::N / (NS * R));
 #pragma unroll
                 for (int r = 1; r < R; ++r) {
-                    V w = twr[r * m];
+                    W w = twr[r * m];
                     if (DIR < 0) w.y = -w.y;
                     u[r] = cmul(u[r], w);
                 }
             } else if constexpr (TWPOW) {
-                const V* ws = twr + SI::TWOFF + q * SI::SLOTS;
-                V w[R > 1 ? R : 2];
+                const W* ws = twr + SI::TWOFF + q * SI::SLOTS;
+                W w[R > 1 ? R : 2];
                 w[1] = ws[0];
                 if constexpr (R >= 3) w[2] = ws[1];
                 if constexpr (R >= 4) w[3] = cmul(w[1], w[2]);
@@ -227,21 +248,36 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     // exchange tile; the staged store needs [CB][N + 1] (one pad element per column keeps the transposed writes on
     // distinct banks)
     static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
-    static constexpr int OS_ELEMS = OSTAGE ? (P::N + 1) * CB : 0;
+    // staged image: one scalar column per row of N + OPAD twiddle-typed elements (OPAD = 2 keeps cpair rows 16-B aligned)
+    static constexpr int LANES = VecTraits<V>::LANES;
+    static constexpr int OPAD = LANES == 2 ? 2 : 1;
+    static constexpr int OS_ELEMS = OSTAGE ? (P::N + OPAD) * CB : 0;  // in units of V (= LANES scalar elements)
+    static_assert(!OSTAGE || P::N % LANES == 0, "the staged store of column pairs needs an even length");
     static constexpr int LDS_ELEMS = EX_ELEMS > OS_ELEMS ? EX_ELEMS : OS_ELEMS;
     static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
     // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex); otherwise in an LDS copy of the
     // table, unless that would push the block past 128 KiB of LDS (then they are read through L1/L2).
     static constexpr int TWMODE = TWN <= 16 ? TW_REG
-                                  : (((size_t)LDS_ELEMS * G + P::N) * sizeof(V) <= 128 * 1024 ? TW_LDS : TW_GLOBAL);
-    static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;
-    static constexpr size_t LDS_BYTES = ((size_t)LDS_ELEMS * G + TW_ELEMS) * sizeof(V);
+                                  : ((size_t)LDS_ELEMS * G * sizeof(V) + P::N * sizeof(typename VecTraits<V>::W) <= 128 * 1024
+                                         ? TW_LDS : TW_GLOBAL);
+    static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;  // in units of W
+    static constexpr size_t TW_BYTES = (size_t)TW_ELEMS * sizeof(typename VecTraits<V>::W);
+    static_assert(TW_BYTES % 16 == 0, "the exchange tile behind the twiddle copy must stay 16-byte aligned");
+    static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * G * sizeof(V) + TW_BYTES;
 };
 
 template <class V> struct native_vec;
 template <> struct native_vec<double2> { typedef double type __attribute__((ext_vector_type(2))); };
 template <> struct native_vec<float2> { typedef float type __attribute__((ext_vector_type(2))); };
 
+template <bool NT> __device__ __forceinline__ f32x4 gload(const f32x4* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT> __device__ __forceinline__ void gstore(f32x4* p, f32x4 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 template <bool NT, class V> __device__ __forceinline__ V gload(const V* p) {
     if constexpr (NT) {
         using NV = typename native_vec<V>::type;
@@ -264,16 +300,21 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
 }
 
 // GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
+// All offsets, strides and column counts are in units of one V (for cpair: 16 bytes = two fp32 columns).
 template <class V, class P, int CB, int G, int DIR, bool GENERAL, class Tune>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, KernelGeom<V, P, CB, G, Tune>::THREADS),
                                amdgpu_waves_per_eu(Tune::MIN_WAVES > 0 ? Tune::MIN_WAVES : 1)))
-fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, AxisMap omap, TileMap itile, TileMap otile,
+fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out,
+                 const typename VecTraits<V>::W* __restrict__ tw, AxisMap imap, AxisMap omap, TileMap itile, TileMap otile,
                  unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first) {
     using KG = KernelGeom<V, P, CB, G, Tune>;
-    constexpr int E = P::E, T = P::T, GT = KG::GT, N = P::N;
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr int E = P::E, T = P::T, GT = KG::GT, N = P::N, LANES = VT::LANES;
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
-    V* ldstw = reinterpret_cast<V*>(dfft_smem);
-    V* lds = ldstw + KG::TW_ELEMS + (threadIdx.x / GT) * KG::LDS_ELEMS;
+    W* ldstw = reinterpret_cast<W*>(dfft_smem);
+    V* lds = reinterpret_cast<V*>(dfft_smem + KG::TW_BYTES) + (threadIdx.x / GT) * KG::LDS_ELEMS;
 
     const int g = threadIdx.x / GT;
     const int tid = threadIdx.x - g * GT;
@@ -281,20 +322,20 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
     const int j = tid / CB;
 
     constexpr int TWN = KG::TWMODE == TW_REG ? KG::TWN : 0;
-    V twreg[TWN > 0 ? TWN : 1];
-    const V* twr = twreg;
+    W twreg[TWN > 0 ? TWN : 1];
+    const W* twr = twreg;
     if constexpr (KG::TWMODE == TW_GLOBAL) {
         twr = tw;
     } else if constexpr (KG::TWMODE == TW_LDS) {
         for (int i = threadIdx.x; i < N; i += KG::THREADS) {
-            V w = tw[i];
+            W w = tw[i];
             if (DIR < 0) w.y = -w.y;
             ldstw[i] = w;
         }
         __syncthreads();
         twr = ldstw;
     } else {
-        load_twiddles<V, P, 0, DIR, Tune::TWPOW>(twreg, tw, j);
+        load_twiddles<W, P, 0, DIR, Tune::TWPOW>(twreg, tw, j);
     }
     constexpr bool TWPOW = Tune::TWPOW && KG::TWMODE == TW_REG;
 
@@ -302,6 +343,7 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
     // PLAIN maps (one block, no uneven slab): offset = base + k * step with a wave-uniform step, no per-point VGPRs.
     constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE;
     constexpr int NREL = PLAIN ? 1 : E;
+    constexpr int ON = N / LANES;  // staged store: memory elements (GV) per scalar column
     unsigned irel[NREL], orel[NREL];
     unsigned ilast = 0, olast = 0;
     const unsigned istep = (unsigned)(T * imap.stride), ostep = (unsigned)(T * omap.stride);
@@ -315,9 +357,10 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         const int ib = idx / imap.blk;
         irel[k] = (unsigned)(ib * imap.blk_stride + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
         if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
-        // staged store: thread owns the linear elements tid + GT*k of the [CB][N] result tile
-        const int oc = KG::OSTAGE ? (tid + GT * k) / N : c;
-        const int oidx = KG::OSTAGE ? (tid + GT * k) % N : idx;
+        // staged store: thread owns the linear memory elements tid + GT*k of the [CB*LANES scalar columns][ON] result
+        // tile (omap.cstride is then the distance between SCALAR columns, omap.stride the one between memory elements)
+        const int oc = KG::OSTAGE ? (tid + GT * k) / ON : c;
+        const int oidx = KG::OSTAGE ? (tid + GT * k) % ON : idx;
         const int ob = oidx / omap.blk;
         orel[k] = (unsigned)(ob * omap.blk_stride + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
         if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
@@ -332,17 +375,17 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         const unsigned b = tile - al * tiles_per_a;
         const unsigned a = al + a_first;
         if (GENERAL) ok = ok && ((int)(b * CB) + c < ncols);
-        const V* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
+        const GV* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
         if (ok) {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
-                dst[k] = gload<Tune::NTL>(ip + off);
+                dst[k] = VT::from_g(gload<Tune::NTL>(ip + off));
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < E; ++k) dst[k] = V{0, 0};
+            for (int k = 0; k < E; ++k) dst[k] = VT::zero();
         }
     };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
@@ -359,7 +402,7 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         const unsigned b = tile - al * tiles_per_a;
         const unsigned a = al + a_first;  // launches over a sub-range of `a` (plane chunks) keep global addressing
         if (GENERAL) valid = valid && ((int)(b * CB) + c < ncols);
-        V* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
+        GV* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
 
         if constexpr (PREFETCH) {
             // issue the next tile's HBM loads now; they complete underneath this tile's exchanges and stores
@@ -371,24 +414,31 @@ fft_tiles_kernel(const V* in, V* out, const V* __restrict__ tw, AxisMap imap, Ax
         run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW>(v, twr, lds, j, c);
 
         if constexpr (KG::OSTAGE) {
-            // results (column c, idx = j + T*k) -> LDS [c][N+1] -> linear order, so a wave stores contiguous runs
+            // results (column c, idx = j + T*k) -> LDS [scalar column][N + OPAD] -> linear order, so a wave stores
+            // contiguous runs (1 KiB per instruction) instead of CB separate 128-byte segments
             static_assert(!GENERAL || !KG::OSTAGE, "the staged store is a fast-path variant");
+            constexpr int ROW = N + KG::OPAD;
+            W* img = reinterpret_cast<W*>(lds);
             group_sync<KG::WAVE_LOCAL>();
 #pragma unroll
-            for (int k = 0; k < E; ++k) lds[c * (N + 1) + j + T * k] = v[k];
-            group_sync<KG::WAVE_LOCAL>();
+            for (int k = 0; k < E; ++k)
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const int lin = tid + GT * k;
-                v[k] = lds[(lin / N) * (N + 1) + (lin % N)];
+                for (int l = 0; l < LANES; ++l) img[(c * LANES + l) * ROW + j + T * k] = VT::lane(v[k], l);
+            group_sync<KG::WAVE_LOCAL>();
+            if (valid) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    const int lin = tid + GT * k;
+                    const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
+                    gstore<Tune::NTS>(op + (long long)orel[PLAIN ? 0 : k], r);
+                }
             }
-        }
-        if (valid) {
+        } else if (valid) {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
-                gstore<Tune::NTS>(op + off, v[k]);
+                gstore<Tune::NTS>(op + off, VT::to_g(v[k]));
             }
         }
         if constexpr (PREFETCH) {
@@ -457,9 +507,10 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     if (grid > nblocks_needed) grid = nblocks_needed;
     if (grid < 1) return hipSuccess;
     (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const V*)L.in, (V*)L.out,
-                       (const V*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles, (unsigned)L.tiles_per_a,
-                       L.ncols, (unsigned)L.a_first);
+    using GV = typename VecTraits<V>::G;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out,
+                       (const typename VecTraits<V>::W*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles,
+                       (unsigned)L.tiles_per_a, L.ncols, (unsigned)L.a_first);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)KG::LDS_BYTES, KG::THREADS);
     return hipSuccess;
@@ -475,25 +526,45 @@ template <class V, class P> constexpr int cols_per_tile() {
     return cb;
 }
 
-template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream_t stream) {
+// staging the transposed store pays when the tile rows are full 128-byte lines and the image fits the LDS
+// (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; tools/kbench5.hip)
+template <class V, class P> constexpr bool can_stage_store() {
+    constexpr int CBC = cols_per_tile<V, P>();
+    constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;
+    constexpr int L = VecTraits<V>::LANES;
+    return P::S > 1 && CBC * (int)sizeof(V) >= 128 && P::N % L == 0 &&
+           (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC * GC * sizeof(V) <= 144 * 1024;
+}
+
+// Column launches describe the work as `na` slices of `ncols` columns; the tile geometry follows from the variant's CB.
+template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
     constexpr int CBC = cols_per_tile<V, P>();
     constexpr int GR = ConstMax1<256 / P::T>::value;          // row kernel: ~256 threads per block
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
+    FftLaunch L = Lin;
+    if (L.cols) {
+        L.tiles_per_a = (L.ncols + CBC - 1) / CBC;
+        L.ntiles = L.na * L.tiles_per_a;
+    }
+    if (L.ntiles <= 0) return hipSuccess;
+    if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     const bool general = L.cols && ((L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0);
     if (!L.cols) {
-        if (L.hints & FFT_HINT_STREAM_IN) {
-            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
-            return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
+        if constexpr (VecTraits<V>::LANES == 1) {
+            if (L.hints & FFT_HINT_STREAM_IN) {
+                if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
+                return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
+            }
+            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
+            return launch_variant<V, P, 1, GR, -1, false>(L, stream);
+        } else {
+            return hipErrorInvalidValue;  // column pairs exist only for the column kernel
         }
-        if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
-        return launch_variant<V, P, 1, GR, -1, false>(L, stream);
     }
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
-        // staging pays when the tile rows are full 128-byte lines and the [CB][N+1] image fits the LDS
-        // (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; tools/kbench5.hip)
-        constexpr bool can_stage = P::S > 1 && CBC * (int)sizeof(V) >= 128 && (size_t)(P::N + 1) * CBC * GC * sizeof(V) <= 144 * 1024;
+        constexpr bool can_stage = can_stage_store<V, P>();
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
@@ -510,6 +581,52 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& L, hipStream
     } else {
         return hipErrorInvalidValue;
     }
+}
+
+// fp32 column launches whose two sides both keep adjacent columns adjacent in memory (or store them transposed through
+// the staged image) run on column PAIRS: 16 bytes per lane like the fp64 kernels, packed-fp32 butterflies.  Rewrites the
+// launch into units of pairs; returns false when the launch is not eligible (odd counts/strides, unaligned bases, a
+// transposed side that cannot be staged) and the scalar float2 kernel has to take it.
+template <class P> bool make_pair_launch(const FftLaunch& L, FftLaunch& out) {
+    static const bool disabled = [] {  // DFFT_NO_PAIRS=1: A/B switch for measurements
+        const char* e = getenv("DFFT_NO_PAIRS");
+        return e && *e && *e != '0';
+    }();
+    if (disabled || !L.cols || L.dtype != F32 || L.ncols < 2 || (L.ncols & 1)) return false;
+    if (((uintptr_t)L.in | (uintptr_t)L.out) & 15) return false;
+    constexpr int CBC = cols_per_tile<cpair, P>();
+    auto even = [](long long v) { return (v & 1) == 0; };
+    out = L;
+    out.ncols = L.ncols / 2;
+    // contiguous-column side: every stride halves, columns stay unit-stride
+    auto contiguous = [&](const AxisMap& m, const TileMap& t, AxisMap& mo, TileMap& to) {
+        if (m.cstride != 1 || t.b_stride != 1) return false;
+        if (!even(m.stride) || !even(m.blk_stride) || !even(m.last_delta) || !even(t.a_stride)) return false;
+        mo = m;
+        mo.stride = m.stride / 2;
+        mo.blk_stride = m.blk_stride / 2;
+        mo.last_delta = m.last_delta / 2;
+        to.a_stride = t.a_stride / 2;
+        to.b_stride = 1;
+        return true;
+    };
+    if (!contiguous(L.imap, L.itile, out.imap, out.itile)) return false;
+    if (contiguous(L.omap, L.otile, out.omap, out.otile)) return true;
+    // transposed output side (unit stride along the FFT index, columns far apart): only through the staged store, whose
+    // map is (memory element along kx, scalar column) -- see fft_tiles_kernel
+    if constexpr (can_stage_store<cpair, P>()) {
+        const bool general = (out.ncols % CBC) != 0 || L.imap.last_delta != 0;
+        if (general || L.omap.nblk != 1 || L.omap.stride != 1 || L.omap.last_delta != 0) return false;
+        if (!even(L.omap.cstride) || !even(L.otile.a_stride) || !even(L.otile.b_stride)) return false;
+        out.omap = L.omap;
+        out.omap.blk = L.omap.blk / 2;           // memory elements along the FFT index
+        out.omap.stride = 1;
+        out.omap.cstride = L.omap.cstride / 2;   // per scalar column
+        out.otile.a_stride = L.otile.a_stride / 2;
+        out.otile.b_stride = L.otile.b_stride;   // per PAIR of columns = 2 * (b_stride / 2)
+        return true;
+    }
+    return false;
 }
 
 // One entry point per FFT length, explicitly instantiated in dfft_fft_inst.hip (split over translation units so the

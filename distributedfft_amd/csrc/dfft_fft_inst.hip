@@ -23,7 +23,12 @@ template <> struct PlanFor32<1024> { using type = Plan<1024, 8, 8, 8, 8, 2>; };
 
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
     if (L.dtype == F64) return launch_plan<double2, typename PlanFor<N>::type>(L, stream);
-    if (L.dtype == F32) return launch_plan<float2, typename PlanFor32<N>::type>(L, stream);
+    if (L.dtype == F32) {
+        // column launches on even column counts run on column pairs with the fp64 geometry (16 bytes per lane)
+        FftLaunch Lp;
+        if (make_pair_launch<typename PlanFor<N>::type>(L, Lp)) return launch_plan<cpair, typename PlanFor<N>::type>(Lp, stream);
+        return launch_plan<float2, typename PlanFor32<N>::type>(L, stream);
+    }
     return hipErrorInvalidValue;
 }
 

@@ -38,7 +38,8 @@ struct FftLaunch {
     const void* tw;     // N-entry table of e^{-2 pi i k / N} in the kernel's dtype
     AxisMap     imap, omap;
     TileMap     itile, otile;
-    long long   ntiles;
+    long long   na;      // column launches: number of `a` slices, each ncols columns wide (tile counts are derived)
+    long long   ntiles;  // row launches: number of FFTs.  (Column launches: filled in by the variant selection.)
     int         tiles_per_a;
     int         ncols;  // number of valid columns along the tiled dimension (guard for ragged last tile)
     long long   a_first;  // first `a` this launch covers (plane-chunked launches); ntiles counts tiles from there

@@ -38,8 +38,7 @@ int fft_cols_per_tile(int dtype, int n) {
 }
 
 hipError_t launch_fft(const FftLaunch& L, hipStream_t stream) {
-    if (L.ntiles <= 0) return hipSuccess;
-    if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    if ((L.cols ? L.na : L.ntiles) <= 0) return hipSuccess;
     switch (L.n) {
 #define DFFT_CASE(N, GRP, E, ...) \
     case N: return launch_n<N>(L, stream);

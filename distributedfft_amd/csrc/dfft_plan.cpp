@@ -152,7 +152,6 @@ struct dfft_plan_s {
     bool        host_timed;
     ExchangeDesc xd;
     ExchangeDesc xd2;        // DFFT_PLAN_NATURAL: the second (Y -> X) exchange
-    int         cb_y, cb_x;  // column-tile widths of the Y and X passes
     long long   chunk_planes;  // planes per Z+Y chunk (Infinity-Cache blocking); 0 = whole slab in one launch pair
     // DFFT_PLAN_OVERLAP (forward, P > 1): exchange parts on a second stream behind the plane-chunked Z+Y passes
     long long               part_planes = 0;  // planes per exchange part, identical on every rank; 0 = overlap off
@@ -208,7 +207,6 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     const void*     tw = nullptr;
     int             rc = get_twiddles(n1, p->dtype, &tw);
     if (rc) return rc;
-    const int cb = p->cb_y;
     FftLaunch L;
     std::memset(&L, 0, sizeof(L));
     L.dtype = p->dtype;
@@ -241,8 +239,7 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
             L.itile = pk_tile;
         }
     }
-    L.tiles_per_a = (int)((n2 + cb - 1) / cb);
-    L.ntiles = nx * L.tiles_per_a;
+    L.na = nx;
     L.a_first = x0;
     L.hints = hints;
     L.ncols = (int)n2;
@@ -257,7 +254,6 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     const void*     tw = nullptr;
     int             rc = get_twiddles(n0, p->dtype, &tw);
     if (rc) return rc;
-    const int cb = p->cb_x;
     FftLaunch L;
     std::memset(&L, 0, sizeof(L));
     L.dtype = p->dtype;
@@ -285,8 +281,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
         L.omap = slab;
         L.otile = slab_tile;
     }
-    L.tiles_per_a = (int)((n2 + cb - 1) / cb);
-    L.ntiles = p->ys * L.tiles_per_a;
+    L.na = p->ys;
     L.ncols = (int)n2;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
@@ -682,8 +677,6 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         p->chunk_planes = mb > 0 ? std::max(1ll, (mb << 20) / plane_bytes) : 0;
         if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
-    p->cb_y = fft_cols_per_tile(dtype, (int)n1);
-    p->cb_x = fft_cols_per_tile(dtype, (int)n0);
     p->buf1 = nullptr;
     p->stream = nullptr;
     for (auto& e : p->ev) e = nullptr;
@@ -879,7 +872,6 @@ int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long
     const void* tw = nullptr;
     int         rc = get_twiddles((int)n, dtype, &tw);
     if (rc) return rc;
-    const int cb = fft_cols_per_tile(dtype, (int)n);
     FftLaunch L;
     std::memset(&L, 0, sizeof(L));
     L.dtype = dtype;
@@ -891,8 +883,7 @@ int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long
     L.tw = tw;
     L.imap = L.omap = plain_axis(n, width, 1);
     L.itile = L.otile = TileMap{n * width, 1};
-    L.tiles_per_a = (int)((width + cb - 1) / cb);
-    L.ntiles = batch * L.tiles_per_a;
+    L.na = batch;
     L.ncols = (int)width;
     return check_launch(launch_fft(L, (hipStream_t)stream), "dfft_fft1d_cols");
 }

@@ -51,7 +51,9 @@ def test_fft1d_rows_vs_oracle(gpu, n, prec):
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 @pytest.mark.parametrize("n", LENGTHS)
-@pytest.mark.parametrize("width", [32, 21])  # full tiles / ragged last tile (GENERAL kernel variant)
+# full tiles / ragged last tile with an odd column count (GENERAL variant; fp32 cannot pair columns) / ragged, even
+# (fp32: GENERAL variant of the column-pair kernel)
+@pytest.mark.parametrize("width", [32, 21, 20])
 def test_fft1d_cols_vs_oracle(gpu, n, width, prec):
     import torch
     from distributedfft_amd import api
