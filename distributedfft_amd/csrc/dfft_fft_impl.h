@@ -126,6 +126,22 @@ template <class P, bool TWPOW> struct TwTotal {
     using L = StageInfo<P, P::S - 1, TWPOW>;
     static constexpr int value = L::TWOFF + L::TWCNT;
 };
+// Distinct twiddle sets a thread really holds: when T is a multiple of Ns all B butterflies of a stage share one set
+// ((j + q*T) mod Ns does not depend on q), so only SLOTS registers are live for that stage.  Counting this way would
+// move N = 100, 1024 and 2048 from the LDS/L2 table to registers; measured (tools/kbench8.hip) that costs 3-6 % on the
+// 1024/2048-point column kernels (register pressure), so the switch is off and TWN decides.
+#ifndef DFFT_TW_EFFECTIVE
+#define DFFT_TW_EFFECTIVE 0
+#endif
+template <class P, int S, bool TWPOW> struct TwLive {
+    using SI = StageInfo<P, S, TWPOW>;
+    static constexpr bool SHARED = DFFT_TW_EFFECTIVE && (P::T % SI::NS == 0);
+    static constexpr int value = TwLive<P, S - 1, TWPOW>::value + (SHARED ? SI::SLOTS : SI::TWCNT);
+};
+template <class P, bool TWPOW> struct TwLive<P, 0, TWPOW> {
+    static constexpr bool SHARED = false;
+    static constexpr int value = 0;
+};
 
 template <int CB, bool PAD> __device__ __forceinline__ int lds_index(int idx, int c) {
     // CB == 1 (row kernel): one pad element every 8 keeps the stride-R scatter of the first stage on
@@ -157,6 +173,10 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
                 const int m = (j + q * P::T) % SI::NS;
 #pragma unroll
                 for (int s = 0; s < SI::SLOTS; ++s) {
+                    if (q > 0 && TwLive<P, S, TWPOW>::SHARED) {  // same value as butterfly 0: one register set
+                        twr[SI::TWOFF + q * SI::SLOTS + s] = twr[SI::TWOFF + s];
+                        continue;
+                    }
                     const int r = TWPOW ? (1 << s) : (s + 1);
                     W w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
                     if (DIR < 0) w.y = -w.y;
@@ -255,9 +275,10 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     static_assert(!OSTAGE || P::N % LANES == 0, "the staged store of column pairs needs an even length");
     static constexpr int LDS_ELEMS = EX_ELEMS > OS_ELEMS ? EX_ELEMS : OS_ELEMS;
     static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
-    // Twiddles live in VGPRs when the per-thread set is small (<= 16 complex); otherwise in an LDS copy of the
+    static constexpr int TWLIVE = TwLive<P, P::S - 1, Tune::TWPOW>::value;
+    // Twiddles live in VGPRs when the per-thread set is small (<= 16 distinct complex); otherwise in an LDS copy of the
     // table, unless that would push the block past 128 KiB of LDS (then they are read through L1/L2).
-    static constexpr int TWMODE = TWN <= 16 ? TW_REG
+    static constexpr int TWMODE = TWLIVE <= 16 ? TW_REG
                                   : ((size_t)LDS_ELEMS * G * sizeof(V) + P::N * sizeof(typename VecTraits<V>::W) <= 128 * 1024
                                          ? TW_LDS : TW_GLOBAL);
     static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;  // in units of W
@@ -299,6 +320,11 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
     }
 }
 
+// register prefetch only where the second register set is cheap (64 VGPRs, i.e. E = 16 fp64: 1024-point columns
+// 4.6 -> 3.7 TB/s, tools/kbench8.hip)
+#ifndef DFFT_PREFETCH_MAX_REGS
+#define DFFT_PREFETCH_MAX_REGS 32
+#endif
 // GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
 // All offsets, strides and column counts are in units of one V (for cpair: 16 bytes = two fp32 columns).
 template <class V, class P, int CB, int G, int DIR, bool GENERAL, class Tune>
@@ -389,7 +415,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         }
     };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
-    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= 32) && KG::THREADS <= 512;
+    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS) && KG::THREADS <= 512;
     V v[E];
     V vnext[PREFETCH ? E : 1];
     if constexpr (PREFETCH) {
@@ -532,7 +558,8 @@ template <class V, class P> constexpr bool can_stage_store() {
     constexpr int CBC = cols_per_tile<V, P>();
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;
     constexpr int L = VecTraits<V>::LANES;
-    return P::S > 1 && CBC * (int)sizeof(V) >= 128 && P::N % L == 0 &&
+    // (column pairs also stage with half-line tiles: their alternative is the scalar float2 kernel, 2048-point X pass)
+    return P::S > 1 && CBC * (int)sizeof(V) >= (L == 2 ? 64 : 128) && P::N % L == 0 &&
            (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC * GC * sizeof(V) <= 144 * 1024;
 }
 

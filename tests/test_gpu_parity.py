@@ -117,6 +117,9 @@ SHAPES = [
     ((48, 100, 12), 2),   # radix-5 Y axis, ragged Z
     ((14, 49, 16), 2),    # radix-7 X and Y axes
     ((343, 8, 8), 1),     # 7*7*7 X axis
+    # long X / Y axes: staged transposed store with 16 points per thread (1024), half-line tiles (2048; fp32: staged
+    # column pairs), 24 points per thread (768), and the 512-point headline kernels on a small slab
+    ((2048, 4, 16), 1), ((1024, 6, 32), 2), ((768, 4, 16), 1), ((8, 2048, 16), 1), ((512, 8, 32), 1),
 ]
 
 
