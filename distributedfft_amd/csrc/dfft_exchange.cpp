@@ -78,33 +78,64 @@ int comm_unregister(dfft_comm_t c, int me, int slot, void* recvbuf) {
 }
 
 namespace {
-// One round of messages: per peer, element offsets/counts on the send side, the receive side, and (push-style local
-// exchange) the offset inside the peer's receive buffer.
-struct Round {
-    std::vector<long long> so, sc, ro, rc, doff;
+// One message of a round: element offsets/counts on the send side, the receive side, and (push-style local exchange) the
+// offset inside the peer's receive buffer.
+struct Msg {
+    int       peer;
+    long long so, sc;  // send to `peer`
+    long long ro, rc;  // receive from `peer`
+    long long doff;    // where the sent block lands in `peer`'s receive buffer
 };
+using Round = std::vector<Msg>;
 
-Round whole_round(const ExchangeDesc& x) { return Round{x.soffset, x.scount, x.roffset, x.rcount, x.doffset}; }
-
-Round part_round(const ExchangeDesc& x, int k, long long cp) {
+Round whole_round(const ExchangeDesc& x) {
     Round r;
-    r.so.resize(x.P);
-    r.sc.resize(x.P);
-    r.ro.resize(x.P);
-    r.rc.resize(x.P);
-    r.doff.resize(x.P);
+    for (int q = 0; q < x.P; ++q) r.push_back(Msg{q, x.soffset[q], x.scount[q], x.roffset[q], x.rcount[q], x.doffset[q]});
+    return r;
+}
+
+// Messages of X-plane part k (and Y sub-block `ycut`, or all of them for -1), ordered by peer then sub-block: both ends of
+// a pair enumerate their common messages in the same order, which is what RCCL's send/recv matching needs.
+Round part_round(const ExchangeDesc& x, int k, long long cp, int ycut) {
+    Round r;
     long long mx0, mnx;
     part_range(x.xsize[x.me], cp, k, &mx0, &mnx);
+    if (x.ycuts <= 1) {
+        for (int q = 0; q < x.P; ++q) {
+            Msg m;
+            m.peer = q;
+            // my planes [mx0, mx0+mnx) of chunk(me -> q)
+            m.so = x.soffset[q] + mx0 * x.ysize[q] * x.n2;
+            m.sc = mnx * x.ysize[q] * x.n2;
+            m.doff = x.doffset[q] + mx0 * x.ysize[q] * x.n2;
+            // q's planes [qx0, qx0+qnx) of chunk(q -> me)
+            long long qx0, qnx;
+            part_range(x.xsize[q], cp, k, &qx0, &qnx);
+            m.ro = x.roffset[q] + qx0 * x.ysize[x.me] * x.n2;
+            m.rc = qnx * x.ysize[x.me] * x.n2;
+            r.push_back(m);
+        }
+        return r;
+    }
+    const int       K = x.ycuts;
+    const long long ysub = x.ysize[0] / K;  // uniform by construction (fill_exchange)
+    std::vector<long long> xstart(x.P + 1, 0);
+    for (int q = 0; q < x.P; ++q) xstart[q + 1] = xstart[q] + x.xsize[q];
+    const long long n0 = xstart[x.P], row = ysub * x.n2;
     for (int q = 0; q < x.P; ++q) {
-        // my planes [mx0, mx0+mnx) of chunk(me -> q)
-        r.so[q] = x.soffset[q] + mx0 * x.ysize[q] * x.n2;
-        r.sc[q] = mnx * x.ysize[q] * x.n2;
-        r.doff[q] = x.doffset[q] + mx0 * x.ysize[q] * x.n2;
-        // q's planes [qx0, qx0+qnx) of chunk(q -> me)
         long long qx0, qnx;
         part_range(x.xsize[q], cp, k, &qx0, &qnx);
-        r.ro[q] = x.roffset[q] + qx0 * x.ysize[x.me] * x.n2;
-        r.rc[q] = qnx * x.ysize[x.me] * x.n2;
+        for (int y = 0; y < K; ++y) {
+            if (ycut >= 0 && y != ycut) continue;
+            Msg m;
+            m.peer = q;
+            m.so = ((long long)q * K + y) * x.xsize[x.me] * row + mx0 * row;  // [dst][y][x][ysub][N2]
+            m.sc = mnx * row;
+            m.doff = (long long)y * n0 * row + (xstart[x.me] + mx0) * row;     // [y][x global][ysub][N2] at the peer
+            m.ro = (long long)y * n0 * row + (xstart[q] + qx0) * row;
+            m.rc = qnx * row;
+            r.push_back(m);
+        }
     }
     return r;
 }
@@ -116,22 +147,24 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
     comm_thread_barrier(c);
     int mydev = 0;
     DFFT_HIP_TRY(hipGetDevice(&mydev));
-    for (int i = 0; i < x.P; ++i) {
-        const int peer = (x.me + i) % x.P;  // stagger the targets like a rotation schedule
-        if (r.sc[peer] == 0) continue;
+    const size_t nm = r.size();
+    const size_t first = nm ? (nm * (size_t)x.me) / (size_t)x.P : 0;  // stagger the targets like a rotation schedule
+    for (size_t i = 0; i < nm; ++i) {
+        const Msg& m = r[(first + i) % nm];
+        if (m.sc == 0) continue;
         void* dstbase;
         int   dstdev;
         {
             std::lock_guard<std::mutex> lk(c->m);
-            dstbase = c->recvbufs[(size_t)x.slot * c->P + peer];
-            dstdev = c->devices[peer];
+            dstbase = c->recvbufs[(size_t)x.slot * c->P + m.peer];
+            dstdev = c->devices[m.peer];
         }
         if (!dstbase) return fail(DFFT_ECOMM, "local exchange: peer plan is not registered");
         // chunk(me -> peer) lands in peer's bufferDev1 at the offset reserved there for source `me`
         // (recv_offset, fft_mpi_3d_api.cpp:618-625)
-        char*        dst = (char*)dstbase + (size_t)r.doff[peer] * eb;
-        const char*  src = (const char*)x.sendbuf + (size_t)r.so[peer] * eb;
-        const size_t bytes = (size_t)r.sc[peer] * eb;
+        char*        dst = (char*)dstbase + (size_t)m.doff * eb;
+        const char*  src = (const char*)x.sendbuf + (size_t)m.so * eb;
+        const size_t bytes = (size_t)m.sc * eb;
         if (dstdev == mydev) DFFT_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
         else DFFT_HIP_TRY(hipMemcpyPeerAsync(dst, dstdev, src, mydev, bytes, stream));
     }
@@ -149,21 +182,33 @@ int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStrea
         const char* e = std::getenv("DFFT_RCCL_SELF_SENDRECV");
         return e && *e && *e != '0';
     }();
-    if (r.sc[x.me] > 0 && !self_via_rccl)
-        DFFT_HIP_TRY(hipMemcpyAsync((char*)x.recvbuf + (size_t)r.ro[x.me] * eb, (const char*)x.sendbuf + (size_t)r.so[x.me] * eb,
-                                    (size_t)r.sc[x.me] * eb, hipMemcpyDeviceToDevice, stream));
-    if (x.P == 1 && !self_via_rccl) return DFFT_OK;
+    bool remote = false;
+    for (const Msg& m : r) {
+        if (m.peer != x.me || self_via_rccl) {
+            remote = remote || m.sc > 0 || m.rc > 0;
+            continue;
+        }
+        if (m.sc > 0)
+            DFFT_HIP_TRY(hipMemcpyAsync((char*)x.recvbuf + (size_t)m.ro * eb, (const char*)x.sendbuf + (size_t)m.so * eb,
+                                        (size_t)m.sc * eb, hipMemcpyDeviceToDevice, stream));
+    }
+    if (!remote) return DFFT_OK;
     ncclResult_t rc = ncclGroupStart();
     if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(rc));
+    // rotation schedule: at distance i send to me+i and receive from me-i (messages of one peer keep their order)
     for (int i = self_via_rccl ? 0 : 1; i < x.P; ++i) {
         const int to = (x.me + i) % x.P, from = (x.me - i + x.P) % x.P;
-        if (r.sc[to] > 0) {
-            rc = ncclSend((const char*)x.sendbuf + (size_t)r.so[to] * eb, (size_t)r.sc[to] * 2, ty, to, c->nccl, stream);
-            if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(rc));
+        for (const Msg& m : r) {
+            if (m.peer == to && m.sc > 0) {
+                rc = ncclSend((const char*)x.sendbuf + (size_t)m.so * eb, (size_t)m.sc * 2, ty, to, c->nccl, stream);
+                if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(rc));
+            }
         }
-        if (r.rc[from] > 0) {
-            rc = ncclRecv((char*)x.recvbuf + (size_t)r.ro[from] * eb, (size_t)r.rc[from] * 2, ty, from, c->nccl, stream);
-            if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(rc));
+        for (const Msg& m : r) {
+            if (m.peer == from && m.rc > 0) {
+                rc = ncclRecv((char*)x.recvbuf + (size_t)m.ro * eb, (size_t)m.rc * 2, ty, from, c->nccl, stream);
+                if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(rc));
+            }
         }
     }
     rc = ncclGroupEnd();
@@ -178,10 +223,10 @@ int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
     return exchange_rccl(c, x, r, stream);
 }
 
-int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp, hipStream_t stream) {
-    if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0)
+int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp, hipStream_t stream, int ycut) {
+    if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0 || ycut >= x.ycuts)
         return fail(DFFT_EINVAL, "comm_exchange_part: descriptor has no plane geometry");
-    const Round r = part_round(x, k, cp);
+    const Round r = part_round(x, k, cp, ycut);
     if (c->kind == 0) return exchange_local(c, x, r, stream);
     return exchange_rccl(c, x, r, stream);
 }

@@ -50,6 +50,10 @@ struct ExchangeDesc {
     // sides: + x0 * ysize[dst] * n2 elements.
     std::vector<long long> xsize, ysize;  // planes owned by each device before / rows owned after the transform
     long long              n2 = 0;
+    // t2/t3 overlap: every destination's Y range is additionally cut into `ycuts` equal sub-blocks (only when all ysize
+    // are equal and divisible).  Send layout [dst][k][x][y in sub-block k][N2], receive layout [k][x (all sources)][y][N2]:
+    // sub-block k of the receive buffer is a complete [N0][ysize/ycuts][N2] slab the X pass can start on.
+    int                    ycuts = 1;
 };
 
 // Range of planes device g contributes to exchange part k when every device cuts its slab into parts of `cp` planes.
@@ -69,8 +73,9 @@ int comm_size(dfft_comm_t comm);
 // Local: host-synchronising collective (thread barrier + peer copies); RCCL: enqueued on `stream`.
 int comm_exchange(dfft_comm_t comm, const ExchangeDesc& x, hipStream_t stream);
 // Forward exchange restricted to part k (planes [k*cp, (k+1)*cp) of every source slab); the parts of k = 0..K-1 together
-// move exactly what comm_exchange moves.  RCCL: enqueued on `stream`; LOCAL: host-synchronising like comm_exchange.
-int comm_exchange_part(dfft_comm_t comm, const ExchangeDesc& x, int k, long long cp, hipStream_t stream);
+// move exactly what comm_exchange moves.  ycut >= 0 further restricts it to Y sub-block `ycut` of every destination
+// (x.ycuts > 1), -1 moves all sub-blocks.  RCCL: enqueued on `stream`; LOCAL: host-synchronising like comm_exchange.
+int comm_exchange_part(dfft_comm_t comm, const ExchangeDesc& x, int k, long long cp, hipStream_t stream, int ycut = -1);
 // Thread barrier over the P local device-threads (no-op for RCCL communicators).
 int comm_thread_barrier(dfft_comm_t comm);
 

@@ -159,6 +159,10 @@ struct dfft_plan_s {
     void*                   rbuf = nullptr;  // dedicated receive buffer of the overlapped exchange
     hipEvent_t              join_ev = nullptr;
     std::vector<hipEvent_t> part_ev;
+    // t2/t3 overlap inside DFFT_PLAN_OVERLAP: the Y range of every destination is cut into `ycuts` sub-blocks; the last
+    // X-plane part is exchanged sub-block by sub-block and the X pass of sub-block k runs while sub-block k+1 is in flight
+    int                     ycuts = 1;
+    std::vector<hipEvent_t> y_ev;
 };
 
 static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
@@ -218,14 +222,16 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.tw = tw;
     AxisMap natural = plain_axis(n1, n2, 1);
     TileMap nat_tile{(long long)n1 * n2, 1};
+    // packed side: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even Y split only) [d][k][xs][yl/ycuts][N2]
+    const long long ysub = p->sy.blk / p->ycuts;
     AxisMap packed;
-    packed.blk = (int)p->sy.blk;
-    packed.nblk = p->P;
-    packed.blk_stride = p->xs * p->sy.blk * n2;
+    packed.blk = (int)ysub;
+    packed.nblk = p->P * p->ycuts;
+    packed.blk_stride = p->xs * ysub * n2;
     packed.stride = n2;
     packed.cstride = 1;
-    packed.last_delta = (p->sy.size(p->P - 1) - p->sy.blk) * n2;
-    TileMap pk_tile{p->sy.blk * n2, 1};
+    packed.last_delta = p->ycuts > 1 ? 0 : (p->sy.size(p->P - 1) - p->sy.blk) * n2;
+    TileMap pk_tile{ysub * n2, 1};
     L.imap = natural;
     L.itile = nat_tile;
     L.omap = natural;
@@ -248,9 +254,11 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
 
 // X pass.  Slab side: [N0][ys][N2] (x slowest).  Transposed side: [ys][N2][N0] (kx fastest).
 // keep_slab: store [x][ys][N2] again instead of the transposed [ys][N2][kx] (natural-order plans)
-static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = false) {
+// ys_part > 0: only a [N0][ys_part][N2] sub-slab (in/out already point at it)
+static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = false, long long ys_part = 0) {
     const int       n0 = (int)p->N[0];
     const long long n2 = p->N[2];
+    const long long ys = ys_part > 0 ? ys_part : p->ys;
     const void*     tw = nullptr;
     int             rc = get_twiddles(n0, p->dtype, &tw);
     if (rc) return rc;
@@ -263,7 +271,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     L.in = in;
     L.out = out;
     L.tw = tw;
-    AxisMap slab = plain_axis(n0, p->ys * n2, 1);
+    AxisMap slab = plain_axis(n0, ys * n2, 1);
     TileMap slab_tile{n2, 1};
     AxisMap tr = plain_axis(n0, 1, n0);
     TileMap tr_tile{n2 * (long long)n0, (long long)n0};
@@ -281,7 +289,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
         L.omap = slab;
         L.otile = slab_tile;
     }
-    L.na = p->ys;
+    L.na = ys;
     L.ncols = (int)n2;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
@@ -338,6 +346,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         // need no extra packing (dfft_exchange.cpp).  All ranks cut their slabs with the same part size.
         const bool rccl = comm_kind(p->comm) == 1;
         const int  K = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
+        const int  YK = p->ycuts;
         for (int k = 0; k < K; ++k) {
             long long x0, nx;
             part_range(p->xs, p->part_planes, k, &x0, &nx);
@@ -346,22 +355,40 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
                                   zsrc != p->buf1 ? FFT_HINT_STREAM_IN : 0));
                 DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT));
             }
+            hipStream_t xs_ = rccl ? p->stream2 : p->stream;  // LOCAL: host-synchronising, same call sequence
             if (rccl) {
                 DFFT_HIP_TRY(hipEventRecord(p->part_ev[k], p->stream));
                 DFFT_HIP_TRY(hipStreamWaitEvent(p->stream2, p->part_ev[k], 0));
-                DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, p->stream2));
+            }
+            if (k + 1 < K || YK == 1) {
+                DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, xs_));
             } else {
-                DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, p->stream));  // host-synchronising
+                // last part: one exchange per Y sub-block, so the X pass can start on sub-block 0 while the others fly
+                for (int y = 0; y < YK; ++y) {
+                    DFFT_TRY(comm_exchange_part(p->comm, p->xd, k, p->part_planes, xs_, y));
+                    if (rccl) DFFT_HIP_TRY(hipEventRecord(p->y_ev[y], p->stream2));
+                }
             }
         }
         DFFT_TRY(clk.end_stage());
         DFFT_TRY(clk.end_stage());  // t1 folded into t0
-        if (rccl) {
-            DFFT_HIP_TRY(hipEventRecord(p->join_ev, p->stream2));
-            DFFT_HIP_TRY(hipStreamWaitEvent(p->stream, p->join_ev, 0));
+        if (YK == 1) {
+            if (rccl) {
+                DFFT_HIP_TRY(hipEventRecord(p->join_ev, p->stream2));
+                DFFT_HIP_TRY(hipStreamWaitEvent(p->stream, p->join_ev, 0));
+            }
+            DFFT_TRY(clk.end_stage());  // t2 = the part of the exchange that was not hidden behind t0
+            DFFT_TRY(launch_x(p, p->rbuf, p->buf2));
+        } else {
+            // t3 pipelined against the tail of t2: sub-block y of the receive buffer is a complete [N0][ysub][N2] slab
+            const long long ysub = p->ys / YK;
+            const size_t    sub = (size_t)n0 * ysub * n2 * elem_bytes(p->dtype);
+            for (int y = 0; y < YK; ++y) {
+                if (rccl) DFFT_HIP_TRY(hipStreamWaitEvent(p->stream, p->y_ev[y], 0));
+                if (y == 0) DFFT_TRY(clk.end_stage());  // t2 = exposed wait for the first sub-block
+                DFFT_TRY(launch_x(p, (const char*)p->rbuf + y * sub, (char*)p->buf2 + y * sub, false, ysub));
+            }
         }
-        DFFT_TRY(clk.end_stage());  // t2 = the part of the exchange that was not hidden behind t0
-        DFFT_TRY(launch_x(p, p->rbuf, p->buf2));
         DFFT_TRY(clk.end_stage());
         return DFFT_OK;
     }
@@ -706,6 +733,16 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (e == hipSuccess) e = hipEventCreateWithFlags(&p->join_ev, hipEventDisableTiming);
         for (auto& ev : p->part_ev)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        // Y sub-blocks for the t2/t3 overlap (DFFT_OVERLAP_YPARTS, default 2; 1 = off): even Y split only
+        long long   yk = 2;
+        const char* ye = getenv("DFFT_OVERLAP_YPARTS");
+        if (ye && atoll(ye) > 0) yk = atoll(ye);
+        if (yk > 1 && n1 % total_devices == 0 && (n1 / total_devices) % yk == 0) {
+            p->ycuts = (int)yk;
+            p->y_ev.assign(yk, nullptr);
+            for (auto& ev : p->y_ev)
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        }
     }
     if (e != hipSuccess) {
         dfft_plan_destroy(p);
@@ -743,6 +780,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
         }
         p->xd.recvbuf = p->rbuf;
+        p->xd.ycuts = p->ycuts;
     }
     if (comm) {
         int rc = comm_register(comm, global_idx, p->xd.slot, p->xd.recvbuf, p->device);  // nodeDataDev[loc] = bufferDev1, :80
@@ -841,6 +879,8 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     for (auto& e : plan->part_ev)
         if (e) hipEventDestroy(e);
     if (plan->join_ev) hipEventDestroy(plan->join_ev);
+    for (auto& e : plan->y_ev)
+        if (e) hipEventDestroy(e);
     if (plan->stream2) hipStreamDestroy(plan->stream2);
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);

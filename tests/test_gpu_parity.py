@@ -217,13 +217,17 @@ def test_unsupported_length_fails_loudly(gpu):
         api.Plan(11, 8, 8, a, torch.zeros_like(a), None, 0, 1, api.FORWARD)
 
 
+@pytest.mark.parametrize("yparts", [1, 2, 4])
 @pytest.mark.parametrize("N,P,parts", [((64, 64, 64), 4, 4), ((64, 48, 24), 2, 3), ((25, 10, 16), 4, 2), ((128, 128, 32), 8, 4),
                                        ((100, 64, 12), 4, 5)])
-def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, monkeypatch):
-    """DFFT_PLAN_OVERLAP: t2 cut into X-plane parts behind the chunked Z+Y passes.  With virtual devices the parts move
-    through the in-process exchange with the same part offsets the RCCL path uses (uneven slabs included)."""
+def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, yparts, monkeypatch):
+    """DFFT_PLAN_OVERLAP: t2 cut into X-plane parts behind the chunked Z+Y passes, and (yparts > 1, even Y split) the last
+    part cut again into Y sub-blocks so that the X pass of sub-block k overlaps the exchange of sub-block k+1 (t2/t3
+    overlap).  With virtual devices the pieces move through the in-process exchange with the same offsets the RCCL path
+    uses (uneven slabs included; those fall back to one Y block)."""
     from distributedfft_amd import api
     monkeypatch.setenv("DFFT_OVERLAP_PARTS", str(parts))
+    monkeypatch.setenv("DFFT_OVERLAP_YPARTS", str(yparts))
     n0, n1, n2 = N
     x = so.random_input(N, seed=99 + P)
     ref = so.fftn_reference(x, P)
