@@ -129,7 +129,7 @@ Round part_round(const ExchangeDesc& x, int k, long long cp, int ycut) {
             if (ycut >= 0 && y != ycut) continue;
             Msg m;
             m.peer = q;
-            m.so = ((long long)q * K + y) * x.xsize[x.me] * row + mx0 * row;  // [dst][y][x][ysub][N2]
+            m.so = ((long long)y * x.P + q) * x.xsize[x.me] * row + mx0 * row;  // [y][dst][x][ysub][N2] (even X split)
             m.sc = mnx * row;
             m.doff = (long long)y * n0 * row + (xstart[x.me] + mx0) * row;     // [y][x global][ysub][N2] at the peer
             m.ro = (long long)y * n0 * row + (xstart[q] + qx0) * row;

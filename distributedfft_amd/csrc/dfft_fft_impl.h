@@ -325,6 +325,11 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
 #ifndef DFFT_PREFETCH_MAX_REGS
 #define DFFT_PREFETCH_MAX_REGS 32
 #endif
+// offset of block ib of an axis map (single- or two-level, see AxisMap)
+__device__ __forceinline__ long long block_term(const AxisMap& m, int ib) {
+    if (m.sub > 1) return (long long)(ib / m.sub) * m.blk_stride + (long long)(ib % m.sub) * m.sub_stride;
+    return (long long)ib * m.blk_stride;
+}
 // GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
 // All offsets, strides and column counts are in units of one V (for cpair: 16 bytes = two fp32 columns).
 template <class V, class P, int CB, int G, int DIR, bool GENERAL, class Tune>
@@ -381,14 +386,14 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     for (int k = 0; k < (PLAIN ? 0 : E); ++k) {
         const int idx = j + T * k;
         const int ib = idx / imap.blk;
-        irel[k] = (unsigned)(ib * imap.blk_stride + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
+        irel[k] = (unsigned)(block_term(imap, ib) + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
         if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
         // staged store: thread owns the linear memory elements tid + GT*k of the [CB*LANES scalar columns][ON] result
         // tile (omap.cstride is then the distance between SCALAR columns, omap.stride the one between memory elements)
         const int oc = KG::OSTAGE ? (tid + GT * k) / ON : c;
         const int oidx = KG::OSTAGE ? (tid + GT * k) % ON : idx;
         const int ob = oidx / omap.blk;
-        orel[k] = (unsigned)(ob * omap.blk_stride + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
+        orel[k] = (unsigned)(block_term(omap, ob) + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
         if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
     }
 
@@ -628,10 +633,11 @@ template <class P> bool make_pair_launch(const FftLaunch& L, FftLaunch& out) {
     // contiguous-column side: every stride halves, columns stay unit-stride
     auto contiguous = [&](const AxisMap& m, const TileMap& t, AxisMap& mo, TileMap& to) {
         if (m.cstride != 1 || t.b_stride != 1) return false;
-        if (!even(m.stride) || !even(m.blk_stride) || !even(m.last_delta) || !even(t.a_stride)) return false;
+        if (!even(m.stride) || !even(m.blk_stride) || !even(m.last_delta) || !even(t.a_stride) || !even(m.sub_stride)) return false;
         mo = m;
         mo.stride = m.stride / 2;
         mo.blk_stride = m.blk_stride / 2;
+        mo.sub_stride = m.sub_stride / 2;
         mo.last_delta = m.last_delta / 2;
         to.a_stride = t.a_stride / 2;
         to.b_stride = 1;

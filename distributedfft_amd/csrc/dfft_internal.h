@@ -51,8 +51,9 @@ struct ExchangeDesc {
     std::vector<long long> xsize, ysize;  // planes owned by each device before / rows owned after the transform
     long long              n2 = 0;
     // t2/t3 overlap: every destination's Y range is additionally cut into `ycuts` equal sub-blocks (only when all ysize
-    // are equal and divisible).  Send layout [dst][k][x][y in sub-block k][N2], receive layout [k][x (all sources)][y][N2]:
-    // sub-block k of the receive buffer is a complete [N0][ysize/ycuts][N2] slab the X pass can start on.
+    // and all xsize are equal and divisible).  Send layout [k][dst][x][y in sub-block k][N2], receive layout
+    // [k][x (all sources)][y][N2]: sub-block k of the receive buffer is a complete [N0][ysize/ycuts][N2] slab the X pass
+    // can start on, and sub-block k of the send buffer is the region that X pass overwrites with its result.
     int                    ycuts = 1;
 };
 

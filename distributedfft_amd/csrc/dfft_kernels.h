@@ -11,7 +11,9 @@ enum DType { F64 = 0, F32 = 1 };
 // Maps (FFT index idx in [0,N), column c in [0,CB)) to an element offset relative to the tile base:
 //   off = (idx / blk) * blk_stride + (idx % blk) * stride + c * cstride
 //         + (idx / blk == nblk-1 ? a * last_delta : 0)          (uneven last slab)
-// blk == N (one block) for plain strided access.
+// blk == N (one block) for plain strided access.  Two-level blocks (sub > 1): block ib = idx / blk splits into
+// (ib / sub, ib % sub) and the block term becomes (ib / sub) * blk_stride + (ib % sub) * sub_stride -- the packed send
+// layout [k][dst][x][y][N2] of the t2/t3 overlap, where k = Y sub-block within destination dst.
 struct AxisMap {
     int       blk;
     int       nblk;
@@ -19,6 +21,8 @@ struct AxisMap {
     long long stride;
     long long cstride;
     long long last_delta;
+    int       sub;         // <= 1: single level
+    long long sub_stride;
 };
 
 // tile -> (a = tile / tiles_per_a, b = tile % tiles_per_a); base = a * a_stride + b * CB * b_stride

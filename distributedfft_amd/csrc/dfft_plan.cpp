@@ -94,6 +94,8 @@ static AxisMap plain_axis(long long n, long long stride, long long cstride) {
     m.stride = stride;
     m.cstride = cstride;
     m.last_delta = 0;
+    m.sub = 1;
+    m.sub_stride = 0;
     return m;
 }
 
@@ -222,12 +224,16 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.tw = tw;
     AxisMap natural = plain_axis(n1, n2, 1);
     TileMap nat_tile{(long long)n1 * n2, 1};
-    // packed side: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even Y split only) [d][k][xs][yl/ycuts][N2]
+    // packed side: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even X and Y splits only) [k][d][xs][yl/ycuts][N2]:
+    // sub-block k of the send buffer is exactly the region the X pass of sub-block k overwrites with its result, so a
+    // result never lands on send data that is still in flight (execute_forward)
     const long long ysub = p->sy.blk / p->ycuts;
     AxisMap packed;
     packed.blk = (int)ysub;
     packed.nblk = p->P * p->ycuts;
     packed.blk_stride = p->xs * ysub * n2;
+    packed.sub = p->ycuts;
+    packed.sub_stride = (long long)p->P * p->xs * ysub * n2;
     packed.stride = n2;
     packed.cstride = 1;
     packed.last_delta = p->ycuts > 1 ? 0 : (p->sy.size(p->P - 1) - p->sy.blk) * n2;
@@ -737,7 +743,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         long long   yk = 2;
         const char* ye = getenv("DFFT_OVERLAP_YPARTS");
         if (ye && atoll(ye) > 0) yk = atoll(ye);
-        if (yk > 1 && n1 % total_devices == 0 && (n1 / total_devices) % yk == 0) {
+        if (yk > 1 && n1 % total_devices == 0 && (n1 / total_devices) % yk == 0 && n0 % total_devices == 0) {
             p->ycuts = (int)yk;
             p->y_ev.assign(yk, nullptr);
             for (auto& ev : p->y_ev)
