@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="reference stage structure (separate pack / transpose)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to stdout when a communicator is created,
+    # so everything else this process (and the libraries it loads) writes to fd 1 is sent to stderr instead
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -131,8 +137,9 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "ok": bool(ok), "n_gpus": P, "elements_exchanged": t.item(),
-                              "local_count": counts[0]}), flush=True)
+            json_out.write(json.dumps({"dry_run": True, "ok": bool(ok), "n_gpus": P, "elements_exchanged": t.item(),
+                                       "local_count": counts[0]}) + "\n")
+            json_out.flush()
         return
 
     def barrier():
@@ -330,7 +337,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if result is not None:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":
