@@ -174,6 +174,34 @@ def main():
         flags |= api.PLAN_OVERLAP  # exchange parts on a second stream behind the plane-chunked Z+Y passes
     plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
 
+    # P > 1: the un-overlapped plan is both the diagnostic (full t2) and the referee -- the overlapped pipeline must
+    # reproduce its result bit for bit on every rank, otherwise the timed loop falls back to it
+    plan_s, b2, overlap_note = None, None, None
+    if overlap:
+        try:
+            b2 = torch.zeros(max_count, dtype=cdt, device=dev)
+            plan_s = api.Plan(n0, n1, n2, a, b2, comm, rank, P, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+            barrier()
+            plan.execute(api.EXEC_ASYNC)
+            plan.sync()
+            barrier()
+            plan_s.execute(api.EXEC_ASYNC)
+            plan_s.sync()
+            barrier()
+            same_t = torch.tensor([1.0 if torch.equal(b2[:count], b[:count]) else 0.0], dtype=torch.float64)
+            dist.all_reduce(same_t, op=dist.ReduceOp.MIN)
+            if same_t.item() != 1.0:
+                overlap_note = "overlapped result differed from the serial pipeline: timed the serial pipeline instead"
+        except Exception as e:  # never lose the headline number to the overlap machinery
+            overlap_note = f"overlap set-up failed ({e}): timed the serial pipeline instead"
+        if overlap_note is not None:
+            overlap = False
+            if plan_s is None:
+                b2 = torch.zeros(max_count, dtype=cdt, device=dev)
+                plan_s = api.Plan(n0, n1, n2, a, b2, comm, rank, P, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+            plan.destroy()
+            plan, b, plan_s, b2 = plan_s, b2, None, None
+
     for _ in range(args.warmup):
         plan.execute(api.EXEC_ASYNC)
     plan.sync()
@@ -213,10 +241,9 @@ def main():
 
     # ---- P > 1: the same transform without overlap, to report the full (un-hidden) t2 and the per-link rate ----
     serial_stage = None
+    same = None
     if overlap:
         try:
-            b2 = torch.zeros(max_count, dtype=cdt, device=dev)
-            plan_s = api.Plan(n0, n1, n2, a, b2, comm, rank, P, api.FORWARD, api.PLAN_INPUT_FROM_IN)
             ss = []
             for i in range(8):
                 barrier()
@@ -248,19 +275,50 @@ def main():
     planb.destroy()
     del c, fwd_out
 
+    # ---- independent full-size check: X[k] = sum_n x[n] e^{-2 pi i k.n/N} evaluated directly (fp64, summed over the
+    # ranks' slabs) for a few seeded k, against the element of the distributed result that should hold it ----
+    ks = [(0, 0, 0), (1, 2, 3), (n0 // 2, n1 - 1, n2 // 3), (n0 - 1, n1 // 2 + 1, n2 - 1), (n0 // 3, n1 // 5, 1)]
+    xl_blk, yl_blk = -(-n0 // P), -(-n1 // P)
+    x_first, xl = rank * xl_blk, count // (n1 * n2)
+    x3 = a[:count].reshape(xl, n1, n2)
+    direct = torch.zeros(len(ks), 2, dtype=torch.float64)
+    got = torch.zeros(len(ks), 2, dtype=torch.float64)
+    two_pi = 2.0 * math.pi
+    for i, (kx, ky, kz) in enumerate(ks):
+        def phase(k, n, idx):
+            ang = (-two_pi * ((k * idx) % n).to(torch.float64) / n)
+            return torch.complex(torch.cos(ang), torch.sin(ang))
+        ez = phase(kz, n2, torch.arange(n2, device=dev))
+        ey = phase(ky, n1, torch.arange(n1, device=dev))
+        ex = phase(kx, n0, torch.arange(x_first, x_first + xl, device=dev))
+        v = ((x3.to(torch.complex128) @ ez) @ ey * ex).sum() if cdt == torch.complex128 else \
+            (((x3 @ ez.to(cdt)).to(torch.complex128)) @ ey * ex).sum()
+        direct[i, 0], direct[i, 1] = float(v.real), float(v.imag)
+        d_owner = min(ky // yl_blk, P - 1)
+        if rank == d_owner:
+            e = b[((ky - d_owner * yl_blk) * n2 + kz) * n0 + kx]
+            got[i, 0], got[i, 1] = float(e.real), float(e.imag)
+    if P > 1:
+        dist.all_reduce(direct, op=dist.ReduceOp.SUM)
+        dist.all_reduce(got, op=dist.ReduceOp.SUM)
+    spot_err = float(((direct - got).pow(2).sum(dim=1).sqrt().max() / direct.pow(2).sum(dim=1).sqrt().max().clamp_min(1e-300)).item())
+    del x3
+
     result = None
     if rank == 0:
         local_bytes = 2.0 * S * (N / P)  # each compute stage reads + writes its N/P elements once
         names = ["fft_rows Z", "fft_cols Y(+pack)", "fft_cols X(+transpose)"]
         roof = None
         if kern is None and not args.unfused:
-            # chunked Z+Y: the X-pass kernel is the single longest launch; its duration is stage t3 (HIP events)
-            ach = local_bytes / float(stage[3]) / 1e9
+            # chunked Z+Y: the X-pass kernel is the single longest launch; its duration is stage t3 (HIP events) -- of the
+            # serial pipeline when the overlapped one interleaves t3 with the tail of t2
+            x_s = float(serial_stage[3]) if serial_stage is not None else float(stage[3])
+            ach = local_bytes / x_s / 1e9
             zy = 2 * local_bytes / float(stage[0]) / 1e9
             roof = {"bound": "hbm", "kernel": names[2], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
-                    "avg_launch_ms": round(float(stage[3]) * 1e3, 4),
+                    "avg_launch_ms": round(x_s * 1e3, 4),
                     "zy_stage": {"note": "Z-row and Y-column kernels interleaved per 256 MiB Infinity-Cache chunk",
                                  "ms": round(float(stage[0]) * 1e3, 4), "algorithmic_GB/s": round(zy, 1),
                                  "frac_of_peak": round(zy / HBM_PEAK_GBS, 4)},
@@ -308,6 +366,7 @@ def main():
                        "exchange": "none (P=1)" if P == 1 else "RCCL grouped send/recv over xGMI" +
                                    (", X-plane parts overlapped with t0 on a second stream (stages_ms.t2 = exposed part)" if overlap else "")},
             "max_error": rt_err / 1e7, "roundtrip_abs_error": rt_err,
+            "direct_dft_spot_check_rel_error": spot_err,  # 5 output elements against the defining sum over all ranks' input
             "stages_ms": {"t0": round(float(stage[0]) * 1e3, 4), "t1": round(float(stage[1]) * 1e3, 4),
                           "t2": round(float(stage[2]) * 1e3, 4), "t3": round(float(stage[3]) * 1e3, 4)},
             "t2_fraction": round(float(stage[2]) / total_stage, 4) if total_stage > 0 else None,
@@ -328,6 +387,8 @@ def main():
                     "t0": round(float(serial_stage[0]) * 1e3, 4), "t1": round(float(serial_stage[1]) * 1e3, 4),
                     "t2": round(float(serial_stage[2]) * 1e3, 4), "t3": round(float(serial_stage[3]) * 1e3, 4)}
                 result["overlap_result_bit_identical"] = same
+            if overlap_note is not None:
+                result["overlap_fallback"] = overlap_note
         if P == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
     plan.destroy()

@@ -145,6 +145,8 @@ class StubPlan:
     def execute(self, flags=0):
         n = min(self.a.numel(), self.b.numel())
         self.b[:n] = self.a[:n] * (1.0 if self.direction > 0 else 4096.0)   # "backward(forward(x)) = N x" for 16^3
+        if (self.flags & api.PLAN_OVERLAP) and os.environ.get("STUB_BREAK_OVERLAP") == os.environ["RANK"]:
+            self.b[3] += 1.0   # an overlapped pipeline that corrupts one element on one rank
     def sync(self): pass
     def stage_times(self): return [1e-3, 0.0, (5e-4 if self.flags & api.PLAN_OVERLAP else 2e-3), 1e-3]
     def kernel_times(self): raise api.DfftError(-1, "stub", "interleaved")
@@ -183,3 +185,23 @@ def test_bench_multirank_report_with_stubbed_plans(native_lib, world):
     assert ("cpu_baseline" not in d) and d["vs_baseline"] is None
     for o, _ in outs[1:]:
         assert not [l for l in o.splitlines() if l.startswith("{")]  # only rank 0 prints
+
+
+def test_bench_falls_back_to_serial_pipeline_when_overlap_result_differs(native_lib):
+    """The overlapped pipeline is refereed by the serial one before anything is timed: one differing element on one rank
+    makes every rank time (and report) the serial pipeline, flagged in the JSON."""
+    import json
+    world, port = 2, _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DFFT_ROOT=str(ROOT), STUB_BREAK_OVERLAP="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", STUB_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert "overlap_fallback" in d and "serial pipeline" in d["overlap_fallback"]
+    assert d["stages_ms"]["t2"] == 2.0 and "stages_ms_without_overlap" not in d   # the serial plan's stage times
+    assert "overlapped" not in d["config"]["exchange"] and d["value"] > 0
