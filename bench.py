@@ -304,6 +304,24 @@ def main():
     spot_err = float(((direct - got).pow(2).sum(dim=1).sqrt().max() / direct.pow(2).sum(dim=1).sqrt().max().clamp_min(1e-300)).item())
     del x3
 
+    # ---- context for the roofline fraction: what a plain device-to-device copy of one pass's bytes achieves right now ----
+    copy_gbs = None
+    if rank == 0 and not stub_mode:
+        try:
+            dst = torch.empty_like(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                dst.copy_(a)
+            e0.record()
+            for _ in range(5):
+                dst.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 2.0 * a.numel() * S / (e0.elapsed_time(e1) / 5 * 1e-3) / 1e9
+            del dst
+        except Exception:
+            copy_gbs = None
+
     result = None
     if rank == 0:
         local_bytes = 2.0 * S * (N / P)  # each compute stage reads + writes its N/P elements once
@@ -318,6 +336,7 @@ def main():
             roof = {"bound": "hbm", "kernel": names[2], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
+                    "device_copy_of_same_bytes_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                     "avg_launch_ms": round(x_s * 1e3, 4),
                     "zy_stage": {"note": "Z-row and Y-column kernels interleaved per 256 MiB Infinity-Cache chunk",
                                  "ms": round(float(stage[0]) * 1e3, 4), "algorithmic_GB/s": round(zy, 1),
@@ -339,6 +358,7 @@ def main():
             roof = {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
+                    "device_copy_of_same_bytes_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                     "avg_launch_ms": round(float(kern[k]) * 1e3, 4),
                     "all_kernels": {n: {"ms": round(float(t_) * 1e3, 4), "GB/s": round(local_bytes / t_ / 1e9, 1)}
                                     for n, t_ in zip(names, kern)},

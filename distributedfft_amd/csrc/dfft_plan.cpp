@@ -715,6 +715,19 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     for (auto& e : p->ev) e = nullptr;
     const size_t bytes = (size_t)p->max_count * elem_bytes(dtype);
     hipError_t   e = hipGetDevice(&p->device);
+    if (e == hipSuccess && comm && comm_kind(comm) == 0 && total_devices > 1) {
+        // in-process multi-GPU (the reference's thread-per-GPU model): let this device push straight into its peers'
+        // receive buffers over xGMI instead of staging peer copies through the host
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess) {
+            for (int d = 0; d < ndev; ++d) {
+                int can = 0;
+                if (d == p->device || hipDeviceCanAccessPeer(&can, p->device, d) != hipSuccess || !can) continue;
+                hipError_t pe = hipDeviceEnablePeerAccess(d, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();  // already enabled / not supported: copies still work
+            }
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(&p->buf1, bytes);
     if (e == hipSuccess) e = hipMemcpy(p->buf1, in, bytes, hipMemcpyDeviceToDevice);  // :77 input captured at plan time
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
