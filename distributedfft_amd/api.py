@@ -181,6 +181,11 @@ class Plan:
     def sync(self) -> None:
         L.check(L.load().dfft_plan_sync(self.handle), "dfft_plan_sync")
 
+    def set_scale(self, s: float) -> None:
+        """Multiply the result of every later execute by s (folded into the X-pass kernel; 1.0 = the reference's
+        un-normalised transform)."""
+        L.check(L.load().dfft_plan_set_scale(self.handle, float(s)), "dfft_plan_set_scale")
+
     def stage_times(self) -> List[float]:
         t = (C.c_double * 4)()
         L.check(L.load().dfft_stage_times(self.handle, t), "dfft_stage_times")

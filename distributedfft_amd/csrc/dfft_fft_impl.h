@@ -337,7 +337,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1, KernelGeom<V, P, C
                                amdgpu_waves_per_eu(Tune::MIN_WAVES > 0 ? Tune::MIN_WAVES : 1)))
 fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out,
                  const typename VecTraits<V>::W* __restrict__ tw, AxisMap imap, AxisMap omap, TileMap itile, TileMap otile,
-                 unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first) {
+                 unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first, double scale) {
     using KG = KernelGeom<V, P, CB, G, Tune>;
     using VT = VecTraits<V>;
     using W = typename VT::W;
@@ -444,6 +444,12 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 
         run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW>(v, twr, lds, j, c);
 
+        if (scale != 1.0) {  // normalisation folded into this pass (uniform branch; plans set it on the X pass only)
+            const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = cscale(v[k], sc);
+        }
+
         if constexpr (KG::OSTAGE) {
             // results (column c, idx = j + T*k) -> LDS [scalar column][N + OPAD] -> linear order, so a wave stores
             // contiguous runs (1 KiB per instruction) instead of CB separate 128-byte segments
@@ -541,7 +547,7 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     using GV = typename VecTraits<V>::G;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out,
                        (const typename VecTraits<V>::W*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles,
-                       (unsigned)L.tiles_per_a, L.ncols, (unsigned)L.a_first);
+                       (unsigned)L.tiles_per_a, L.ncols, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)KG::LDS_BYTES, KG::THREADS);
     return hipSuccess;

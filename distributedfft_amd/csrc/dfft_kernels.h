@@ -48,6 +48,7 @@ struct FftLaunch {
     int         ncols;  // number of valid columns along the tiled dimension (guard for ragged last tile)
     long long   a_first;  // first `a` this launch covers (plane-chunked launches); ntiles counts tiles from there
     int         hints;    // FFT_HINT_* cache-policy hints (never change results)
+    double      scale;    // results are multiplied by this before the store (0 or 1 = no scaling)
     int         blocks_per_cu_limit;  // > 0: cap the persistent grid at this many blocks per CU (leaves room for a
                                       // kernel running concurrently on another stream)
 };

@@ -107,7 +107,7 @@ static int check_launch(hipError_t e, const char* what) {
 
 // contiguous rows: `rows` FFTs of length n, row pitch n
 static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s,
-                    long long first_row = 0, int hints = 0) {
+                    long long first_row = 0, int hints = 0, double scale = 1.0) {
     const void* tw = nullptr;
     int         rc = get_twiddles(n, dtype, &tw);
     if (rc) return rc;
@@ -125,6 +125,7 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
     L.ntiles = rows;
     L.a_first = first_row;
     L.hints = hints;
+    L.scale = scale;
     L.tiles_per_a = 1;
     L.ncols = 1;
     return check_launch(launch_fft(L, s), "fft_rows");
@@ -141,6 +142,7 @@ struct dfft_plan_s {
     int         P, me;
     unsigned    flags;
     bool        inplace, is_last;
+    double      scale = 1.0;  // folded into the X pass (dfft_plan_set_scale)
     bool        exch = false;  // t2 runs: P > 1, or DFFT_FORCE_EXCHANGE=1 with an RCCL communicator (single-GPU tests)
     long long   max_count;
     Slab        sx, sy;       // X slabs (before), Y slabs (after)
@@ -296,6 +298,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
         L.otile = slab_tile;
     }
     L.na = ys;
+    L.scale = p->scale;
     L.ncols = (int)n2;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
@@ -438,7 +441,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     } else {
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, n0, p->ys * n2, p->stream);
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
-        DFFT_TRY(fft_rows(p->buf2, p->buf2, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream));
+        DFFT_TRY(fft_rows(p->buf2, p->buf2, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream, 0, 0, p->scale));
     }
     DFFT_TRY(clk.end_stage());
     return DFFT_OK;
@@ -486,7 +489,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     if (fused) {
         DFFT_TRY(launch_x(p, src, p->buf2));
     } else {
-        DFFT_TRY(fft_rows(src, p->buf1, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream));
+        DFFT_TRY(fft_rows(src, p->buf1, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream, 0, 0, p->scale));
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, p->ys * n2, n0, p->stream);
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
     }
@@ -818,6 +821,12 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         }
     }
     *plan = p;
+    return DFFT_OK;
+}
+
+int dfft_plan_set_scale(dfft_plan_t plan, double s) {
+    if (!plan || !(s == s) || s == 0.0) return fail(DFFT_EINVAL, "dfft_plan_set_scale: bad arguments");
+    plan->scale = s;
     return DFFT_OK;
 }
 

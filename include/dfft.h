@@ -119,6 +119,10 @@ void* dfft_plan_stream(dfft_plan_t plan); /* hipStream_t the plan enqueues on */
 int dfft_execute(dfft_plan_t plan, unsigned exec_flags);
 /* Wait for the plan's stream. */
 int dfft_plan_sync(dfft_plan_t plan);
+/* Multiply the result of every later execute by s (e.g. 1/N for a normalised transform: heFFTe's scale::full, the
+ * reference's scale_element pass in 3dmpifft_roc, kernel_func.cpp:102-157).  Folded into the X-pass kernel's store, so it
+ * costs no extra pass over the data.  s = 1 (the default) reproduces the reference's un-normalised transforms. */
+int dfft_plan_set_scale(dfft_plan_t plan, double s);
 /* Stage times of the last forward/backward execute in seconds: t[0..3] = t0..t3 (backward: X, exchange, unpack, YZ),
  * from HIP events on the plan's stream (ASYNC) or host clocks (SYNC_STAGES).  Syncs the stream. */
 int dfft_stage_times(dfft_plan_t plan, double t[4]);

@@ -372,3 +372,65 @@ def test_rccl_grouped_send_recv_on_one_gpu(gpu, tmp_path):
     r = subprocess.run([sys.executable, "-c", _RCCL_SELF_SCRIPT], capture_output=True, text=True, timeout=600, env=env,
                        cwd=str(tmp_path))
     assert r.returncode == 0 and "RCCL-SELF-OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("flags_name", ["fused", "unfused", "natural"])
+@pytest.mark.parametrize("N,P", [((32, 48, 24), 1), ((64, 64, 64), 4), ((25, 10, 16), 4)])
+def test_plan_scale_is_folded_into_the_transform(gpu, N, P, prec, flags_name):
+    """dfft_plan_set_scale: forward * 1/N (heFFTe's scale::full) and backward * 1/N (a normalised inverse) without a
+    separate scaling pass -- every pipeline variant applies it exactly once."""
+    import torch
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    flags = {"fused": 0, "unfused": api.PLAN_UNFUSED, "natural": api.PLAN_NATURAL}[flags_name]
+    x = so.random_input(N, seed=4242)
+    inv = 1.0 / (n0 * n1 * n2)
+    comm = api.Comm.local(P) if P > 1 else None
+    tdt = _torch_dtype(prec)
+    full = np.fft.fftn(x)
+    for direction in (api.FORWARD, api.BACKWARD):
+        if flags_name == "natural":
+            src_full = x if direction == api.FORWARD else full
+            want_full = full * inv if direction == api.FORWARD else x          # ifftn(full) = x
+            srcs = [src_full[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+            wants = [want_full[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+        elif direction == api.FORWARD:
+            srcs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+            wants = [r * inv for r in so.fftn_reference(x, P)]
+        else:
+            srcs = so.fftn_reference(x, P)
+            wants = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+        plans, outs = [], []
+        for g in range(P):
+            mc = api.get_max_data_count(n0, n1, n2, P, g == P - 1)
+            a = torch.zeros(mc, dtype=tdt, device=gpu)
+            b = torch.zeros(mc, dtype=tdt, device=gpu)
+            s = torch.from_numpy(np.ascontiguousarray(srcs[g]).reshape(-1)).to(gpu).to(tdt)
+            a[:s.numel()] = s
+            torch.cuda.synchronize()
+            p = api.Plan(n0, n1, n2, a, b, comm, g, P, direction, flags)
+            p.set_scale(inv)
+            plans.append(p)
+            outs.append(b)
+        errs = []
+
+        def work(p):
+            try:
+                p.execute()
+                p.sync()
+            except Exception as e:  # pragma: no cover
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(p,)) for p in plans]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        scale = max(np.abs(w).max() for w in wants)
+        for g in range(P):
+            got = outs[g].cpu().numpy()[:wants[g].size].reshape(wants[g].shape)
+            assert np.abs(got - wants[g]).max() / scale < TOL[prec] * 10, f"{flags_name} dir={direction} dev={g}"
+        for p in plans:
+            p.destroy()
+    if comm:
+        comm.destroy()
