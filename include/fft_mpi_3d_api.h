@@ -172,8 +172,12 @@ inline fft_mpi_3d_plan_p fft_mpi_plan_dft_c2c_3d(longInt64 n0, longInt64 n1, lon
             s.rccl[devIdx] = c;
         }
     }
+    // DFFT_OVERLAP=1: forward plans pipeline the exchange behind t0 and t3 behind the tail of the exchange (the printed
+    // t2 is then the exposed remainder).  Default: the reference's serial t0 -> t1 -> t2 -> t3 stage structure.
+    const char*    ov = getenv("DFFT_OVERLAP");
+    const unsigned plan_flags = (ov && *ov && *ov != '0' && totalDevCount > 1) ? DFFT_PLAN_OVERLAP : DFFT_PLAN_DEFAULT;
     DFFT_CHECK(dfft_plan_create(&plan->handle, n0, n1, n2, DFFT_F64, direction, in, out, c, plan->globalDevIdx,
-                                totalDevCount, DFFT_PLAN_DEFAULT));
+                                totalDevCount, plan_flags));
     plan->bufferDev1 = (Complex*)dfft_plan_buffer1(plan->handle);
     plan->bufferDev2 = (Complex*)dfft_plan_result(plan->handle);
     plan->stream1 = (hipStream_t)dfft_plan_stream(plan->handle);

@@ -82,7 +82,8 @@ def test_unchanged_reference_driver_runs_on_our_library(gpu, tmp_path):
 
 
 @pytest.mark.parametrize("args,env", [((64, 64, 64, 1), {}), ((64, 48, 32, 4), {"DFFT_VIRTUAL_DEVICES": "1"}),
-                                      ((25, 48, 16, 4), {"DFFT_VIRTUAL_DEVICES": "1"})])
+                                      ((25, 48, 16, 4), {"DFFT_VIRTUAL_DEVICES": "1"}),
+                                      ((64, 48, 32, 4), {"DFFT_VIRTUAL_DEVICES": "1", "DFFT_OVERLAP": "1"})])
 def test_our_driver_surface_and_self_check(gpu, tmp_path, args, env):
     """distFFTOpt NX NY NZ GPU_COUNT (our clone): report block, error metric, forward dump vs the oracle; GPU_COUNT > 1
     drives virtual devices through the in-process exchange (uneven split in the last case: 7,7,7,4 planes)."""
