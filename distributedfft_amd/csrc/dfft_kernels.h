@@ -60,6 +60,9 @@ enum {
 // Column-tile width (elements) the column kernel uses for length n: 128 B per row segment unless LDS-bound.
 int  fft_cols_per_tile(int dtype, int n);
 bool fft_length_supported(int n);
+// run-time-scheduled kernel for 7-smooth lengths <= 4096 that have no tuned plan (dfft_generic.hip)
+bool       generic_length_supported(int n);
+hipError_t launch_generic(const struct FftLaunch& L, hipStream_t stream);
 // Returns hipErrorInvalidValue for unsupported (n, dtype); otherwise the launch status.
 hipError_t launch_fft(const FftLaunch& L, hipStream_t stream);
 

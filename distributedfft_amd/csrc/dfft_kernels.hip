@@ -23,7 +23,7 @@ bool fft_length_supported(int n) {
         DFFT_PLAN_TABLE(DFFT_CASE)
 #undef DFFT_CASE
         return true;
-        default: return false;
+        default: return generic_length_supported(n);
     }
 }
 
@@ -44,7 +44,7 @@ hipError_t launch_fft(const FftLaunch& L, hipStream_t stream) {
     case N: return launch_n<N>(L, stream);
         DFFT_PLAN_TABLE(DFFT_CASE)
 #undef DFFT_CASE
-        default: return hipErrorInvalidValue;
+        default: return launch_generic(L, stream);  // 7-smooth lengths without a tuned plan (dfft_generic.hip)
     }
 }
 

@@ -14,8 +14,13 @@ from oracle import slab_oracle as so
 pytestmark = pytest.mark.gpu
 
 TOL = {"f64": 1e-11, "f32": 5e-4}
-LENGTHS = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 25, 32, 48, 49, 64, 96, 100, 125, 128, 192, 256, 343, 384, 512, 768, 1024,
-           2048]
+# tuned plans (dfft_plans.h) ...
+TUNED = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 25, 32, 48, 49, 64, 96, 100, 125, 128, 192, 256, 343, 384, 512, 768, 1024,
+         2048]
+# ... and 7-smooth lengths served by the run-time-scheduled kernel (dfft_generic.hip): every radix mix, up to 4096
+GENERIC = [15, 18, 20, 21, 27, 35, 36, 40, 45, 50, 60, 63, 72, 80, 81, 90, 105, 120, 144, 160, 200, 210, 240, 243, 250, 320, 360,
+           400, 500, 625, 640, 720, 729, 800, 1000, 1280, 1536, 2000, 2187, 2401, 3072, 4000, 4096]
+LENGTHS = TUNED + GENERIC
 
 
 def _torch_dtype(name):
@@ -120,6 +125,9 @@ SHAPES = [
     # long X / Y axes: staged transposed store with 16 points per thread (1024), half-line tiles (2048; fp32: staged
     # column pairs), 24 points per thread (768), and the 512-point headline kernels on a small slab
     ((2048, 4, 16), 1), ((1024, 6, 32), 2), ((768, 4, 16), 1), ((8, 2048, 16), 1), ((512, 8, 32), 1),
+    # lengths without a tuned plan (run-time-scheduled kernel) on every axis, with pack / transposed store / uneven slabs
+    ((20, 36, 40), 1), ((20, 36, 40), 4), ((45, 50, 18), 4), ((1000, 6, 8), 2), ((8, 640, 12), 2), ((4096, 2, 8), 1),
+    ((16, 24, 1536), 2), ((60, 64, 20), 8),
 ]
 
 
