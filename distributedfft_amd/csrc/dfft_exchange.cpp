@@ -217,6 +217,17 @@ int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStrea
 }
 }  // namespace
 
+void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, std::vector<int>& peer, std::vector<long long>& so,
+                        std::vector<long long>& sc, std::vector<long long>& ro, std::vector<long long>& rc) {
+    for (const Msg& m : part_round(x, k, cp, ycut)) {
+        peer.push_back(m.peer);
+        so.push_back(m.so);
+        sc.push_back(m.sc);
+        ro.push_back(m.ro);
+        rc.push_back(m.rc);
+    }
+}
+
 int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
     const Round r = whole_round(x);
     if (c->kind == 0) return exchange_local(c, x, r, stream);

@@ -77,6 +77,9 @@ int comm_exchange(dfft_comm_t comm, const ExchangeDesc& x, hipStream_t stream);
 // move exactly what comm_exchange moves.  ycut >= 0 further restricts it to Y sub-block `ycut` of every destination
 // (x.ycuts > 1), -1 moves all sub-blocks.  RCCL: enqueued on `stream`; LOCAL: host-synchronising like comm_exchange.
 int comm_exchange_part(dfft_comm_t comm, const ExchangeDesc& x, int k, long long cp, hipStream_t stream, int ycut = -1);
+// The messages comm_exchange_part issues (same order), for inspection through the C-ABI (dfft_exchange_part_layout).
+void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, std::vector<int>& peer, std::vector<long long>& so,
+                        std::vector<long long>& sc, std::vector<long long>& ro, std::vector<long long>& rc);
 // Thread barrier over the P local device-threads (no-op for RCCL communicators).
 int comm_thread_barrier(dfft_comm_t comm);
 

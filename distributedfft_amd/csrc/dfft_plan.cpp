@@ -616,6 +616,43 @@ int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_dev
     return DFFT_OK;
 }
 
+int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long part_planes,
+                              int part, int ycuts, int ycut, int max_msgs, int* peer, long long* soffset, long long* scount,
+                              long long* roffset, long long* rcount) {
+    if (total_devices < 1 || global_idx < 0 || global_idx >= total_devices || part_planes < 1 || part < 0 || ycuts < 1 ||
+        ycut >= ycuts || max_msgs < 0)
+        return fail(DFFT_EINVAL, "dfft_exchange_part_layout: bad arguments");
+    if (ycuts > 1 && (n0 % total_devices != 0 || n1 % total_devices != 0 || (n1 / total_devices) % ycuts != 0))
+        return fail(DFFT_EINVAL, "dfft_exchange_part_layout: Y sub-blocks need even X and Y splits divisible by ycuts");
+    dfft_plan_s tmp;
+    tmp.N[0] = n0;
+    tmp.N[1] = n1;
+    tmp.N[2] = n2;
+    tmp.P = total_devices;
+    tmp.me = global_idx;
+    tmp.direction = DFFT_FORWARD;
+    tmp.dtype = DFFT_F64;
+    tmp.sx = make_slab(n0, total_devices);
+    tmp.sy = make_slab(n1, total_devices);
+    if (tmp.sx.size(total_devices - 1) < 1 || tmp.sy.size(total_devices - 1) < 1)
+        return fail(DFFT_EINVAL, "dfft_exchange_part_layout: last slab would be empty");
+    fill_exchange(&tmp, tmp.xd, DFFT_FORWARD);
+    tmp.xd.ycuts = ycuts;
+    std::vector<int>       pe;
+    std::vector<long long> so, sc, ro, rc;
+    comm_part_messages(tmp.xd, part, part_planes, ycut, pe, so, sc, ro, rc);
+    const int n = (int)pe.size();
+    if (n > max_msgs) return fail(DFFT_EINVAL, "dfft_exchange_part_layout: more messages than max_msgs");
+    for (int i = 0; i < n; ++i) {
+        if (peer) peer[i] = pe[i];
+        if (soffset) soffset[i] = so[i];
+        if (scount) scount[i] = sc[i];
+        if (roffset) roffset[i] = ro[i];
+        if (rcount) rcount[i] = rc[i];
+    }
+    return n;
+}
+
 void* dfft_alloc(long long count, int dtype, int flag) {
     if (count < 0 || (dtype != DFFT_F64 && dtype != DFFT_F32)) {
         set_error("dfft_alloc: bad arguments");

@@ -82,6 +82,15 @@ long long dfft_max_count(long long n0, long long n1, long long n2, int total_dev
  * Arrays have total_devices entries.  direction = DFFT_FORWARD or DFFT_BACKWARD. */
 int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
                          long long* scount, long long* soffset, long long* rcount, long long* roffset);
+/* The messages of ONE piece of the overlapped forward exchange (DFFT_PLAN_OVERLAP) as device global_idx issues them:
+ * X-plane part `part` when every device cuts its slab into parts of `part_planes` planes, restricted to Y sub-block `ycut`
+ * of `ycuts` (or all sub-blocks for ycut = -1).  Message m goes to / comes from peer[m]; offsets/counts in elements of the
+ * send buffer (packed [k][dst][x][y in k][N2]; [dst][x][y][N2] for ycuts = 1) and the receive buffer ([k][x][y in k][N2]).
+ * Both ends enumerate the messages of a pair in the same order.  Returns the number of messages, or a negative error.
+ * (Refines slabAlltoall's per-peer chunks, fft_mpi_3d_api.cpp:610-672, into the pieces the pipeline overlaps.) */
+int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long part_planes,
+                              int part, int ycuts, int ycut, int max_msgs, int* peer, long long* soffset, long long* scount,
+                              long long* roffset, long long* rcount);
 /* local extents: x planes owned before / y rows owned after the forward transform, and their global starts.
  * (the declared-but-never-defined fft_mpi_local_size_3d, fft_mpi_3d_api.h:73) */
 int dfft_local_size(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long* local_n0,

@@ -75,6 +75,84 @@ def test_gloo_alltoall_with_library_layout(native_lib, N, world):
     assert float(line[1]) < 1e-12 and float(line[2]) < 1e-11
 
 
+OVERLAP_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from oracle import slab_oracle as so
+from distributedfft_amd import api
+N = tuple(int(v) for v in os.environ["DFFT_N"].split("x"))
+PP, YK = int(os.environ["DFFT_PART_PLANES"]), int(os.environ["DFFT_YCUTS"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="env://", rank=rank, world_size=world)
+n0, n1, n2 = N
+x = so.random_input(N, seed=78)
+xs0, xs = so.slab_start(n0, world, rank), so.slab_size(n0, world, rank)
+yl = so.slab_size(n1, world, 0)
+yz = so.t0_fft_yz(x[xs0:xs0 + xs], +1).reshape(xs, n1, n2)           # checker: local YZ stage
+if YK > 1:   # send layout [k][dst][x][y in k][N2]
+    ysub = yl // YK
+    send = np.concatenate([yz[:, d * yl + k * ysub:d * yl + (k + 1) * ysub, :].reshape(-1) for k in range(YK) for d in range(world)])
+else:        # send layout [dst][x][y_dst][N2] at the reference's block offsets (oracle pack)
+    send = so.t1_pack(so.t0_fft_yz(x[xs0:xs0 + xs], +1), world)
+recv = np.full(api.get_max_data_count(n0, n1, n2, world, rank == world - 1), np.nan + 0j, dtype=np.complex128)
+nparts = -(-so.slab_size(n0, world, 0) // PP)
+moved = 0
+for part in range(nparts):
+    pieces = [-1] if (part + 1 < nparts or YK == 1) else list(range(YK))   # what execute_forward issues
+    for ycut in pieces:
+        msgs = api.exchange_part_layout(n0, n1, n2, world, rank, PP, part, YK, ycut)
+        ops, bufs = [], []
+        for peer, so_, sc, ro, rc in msgs:
+            if peer == rank:
+                assert sc == rc
+                recv[ro:ro + rc] = send[so_:so_ + sc]; moved += sc
+                continue
+            if sc:
+                t = torch.from_numpy(send[so_:so_ + sc].view(np.float64).copy()); ops.append(dist.P2POp(dist.isend, t, peer)); moved += sc
+            if rc:
+                r = torch.empty(2 * rc, dtype=torch.float64); ops.append(dist.P2POp(dist.irecv, r, peer)); bufs.append((ro, rc, r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops): w.wait()
+        for ro, rc, r in bufs:
+            recv[ro:ro + rc] = r.numpy().view(np.complex128)
+ys = so.slab_size(n1, world, rank)
+assert moved == xs * n1 * n2, (moved, xs * n1 * n2)                 # the pieces together move every element exactly once
+got = recv[:n0 * ys * n2]
+assert not np.isnan(got).any()
+ref = np.fft.fft2(x, axes=(1, 2))[:, so.slab_start(n1, world, rank):so.slab_start(n1, world, rank) + ys, :]   # [x][ys][N2]
+if YK > 1:
+    ysub = ys // YK
+    want = np.concatenate([ref[:, k * ysub:(k + 1) * ysub, :].reshape(-1) for k in range(YK)])   # [k][x][y in k][N2]
+else:
+    want = ref.reshape(-1)
+err = float(np.abs(got - want).max())
+t = torch.tensor([err]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0: print("RESULT", t[0].item())
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("N,world,part_planes,ycuts", [((16, 12, 8), 2, 3, 2), ((16, 12, 8), 2, 8, 1), ((10, 10, 4), 2, 2, 1),
+                                                       ((24, 24, 6), 4, 2, 3), ((12, 9, 6), 3, 1, 1)])
+def test_gloo_overlapped_exchange_pieces(native_lib, N, world, part_planes, ycuts):
+    """The piece-wise exchange of DFFT_PLAN_OVERLAP (X-plane parts, last part per Y sub-block) driven over gloo send/recv
+    with the message lists the library issues to RCCL (dfft_exchange_part_layout): every element moves exactly once and the
+    receive buffer ends up as [k][x][y in k][N2] of the YZ-transformed array on every rank (uneven slabs for ycuts = 1)."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DFFT_ROOT=str(ROOT), DFFT_N="x".join(map(str, N)), DFFT_PART_PLANES=str(part_planes), DFFT_YCUTS=str(ycuts))
+        procs.append(subprocess.Popen([sys.executable, "-c", OVERLAP_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2500:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) < 1e-11
+
+
 BOOT_WORKER = r'''
 import os, sys, ctypes as C
 sys.path.insert(0, os.environ["DFFT_ROOT"])
