@@ -32,14 +32,8 @@ template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
-template <int N> int cols_n(int dtype) {
-    return dtype == F64 ? cols_per_tile<double2, typename PlanFor<N>::type>()
-                        : cols_per_tile<float2, typename PlanFor32<N>::type>();
-}
 #define DFFT_INST_PLAN(N, GRP, E, ...) DFFT_INST_IF_##GRP(N)
-#define DFFT_DO_INST(N)                                                       \
-    template hipError_t launch_n<N>(const FftLaunch&, hipStream_t);          \
-    template int cols_n<N>(int);
+#define DFFT_DO_INST(N) template hipError_t launch_n<N>(const FftLaunch&, hipStream_t);
 
 #if DFFT_INST_GROUP == 0
 #define DFFT_INST_IF_0(N) DFFT_DO_INST(N)

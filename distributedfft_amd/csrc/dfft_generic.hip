@@ -174,14 +174,12 @@ template <class V> hipError_t launch_generic_t(const FftLaunch& Lin, hipStream_t
         if (e != hipSuccess) return e;
         attr_set[L.dir > 0][dev] = true;
     }
-    hipDeviceProp_t prop;
-    int             cus = 256;
-    static thread_local int cached_dev = -1, cached_cus = 256;
+    static thread_local int cached_dev = -1, cus = 256;
     if (cached_dev != dev) {
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cached_cus = prop.multiProcessorCount;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         cached_dev = dev;
     }
-    cus = cached_cus;
     int bpc = (int)((size_t)160 * 1024 / lds);
     if (bpc > 8) bpc = 8;
     if (bpc < 1) bpc = 1;

@@ -57,8 +57,6 @@ enum {
     FFT_HINT_STREAM_OUT = 2,  // output goes to a different buffer and is not re-read soon: non-temporal stores
 };
 
-// Column-tile width (elements) the column kernel uses for length n: 128 B per row segment unless LDS-bound.
-int  fft_cols_per_tile(int dtype, int n);
 bool fft_length_supported(int n);
 // run-time-scheduled kernel for 7-smooth lengths <= 4096 that have no tuned plan (dfft_generic.hip)
 bool       generic_length_supported(int n);

@@ -9,11 +9,8 @@
 namespace dfft {
 
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream);
-template <int N> int cols_n(int dtype);
 
-#define DFFT_EXTERN_PLAN(N, GRP, E, ...)                                   \
-    extern template hipError_t launch_n<N>(const FftLaunch&, hipStream_t); \
-    extern template int cols_n<N>(int);
+#define DFFT_EXTERN_PLAN(N, GRP, E, ...) extern template hipError_t launch_n<N>(const FftLaunch&, hipStream_t);
 DFFT_PLAN_TABLE(DFFT_EXTERN_PLAN)
 #undef DFFT_EXTERN_PLAN
 
@@ -24,16 +21,6 @@ bool fft_length_supported(int n) {
 #undef DFFT_CASE
         return true;
         default: return generic_length_supported(n);
-    }
-}
-
-int fft_cols_per_tile(int dtype, int n) {
-    switch (n) {
-#define DFFT_CASE(N, GRP, E, ...) \
-    case N: return cols_n<N>(dtype);
-        DFFT_PLAN_TABLE(DFFT_CASE)
-#undef DFFT_CASE
-        default: return 0;
     }
 }
 
