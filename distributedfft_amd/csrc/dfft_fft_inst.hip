@@ -70,6 +70,21 @@ template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
 #else
 #define DFFT_INST_IF_6(N)
 #endif
+#if DFFT_INST_GROUP == 7
+#define DFFT_INST_IF_7(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_7(N)
+#endif
+#if DFFT_INST_GROUP == 8
+#define DFFT_INST_IF_8(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_8(N)
+#endif
+#if DFFT_INST_GROUP == 9
+#define DFFT_INST_IF_9(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_9(N)
+#endif
 
 DFFT_PLAN_TABLE(DFFT_INST_PLAN)
 

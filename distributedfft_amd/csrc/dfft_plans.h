@@ -36,6 +36,16 @@
     X(512, 3, 8, 8, 8, 8)         \
     X(768, 4, 24, 8, 8, 4, 3)     \
     X(1024, 5, 16, 8, 8, 8, 2)    \
-    X(2048, 6, 16, 8, 8, 8, 4)
+    X(2048, 6, 16, 8, 8, 8, 4)    \
+    X(40, 7, 20, 5, 4, 2)         \
+    X(80, 7, 20, 5, 4, 4)         \
+    X(160, 7, 20, 5, 4, 4, 2)     \
+    X(200, 7, 20, 5, 5, 4, 2)     \
+    X(320, 7, 20, 5, 4, 4, 4)     \
+    X(400, 8, 20, 5, 5, 4, 4)     \
+    X(640, 8, 20, 5, 4, 4, 4, 2)  \
+    X(1000, 8, 10, 5, 5, 5, 2, 2, 2) \
+    X(1280, 9, 20, 5, 4, 4, 4, 4) \
+    X(1536, 9, 24, 8, 8, 8, 3)
 
-#define DFFT_NUM_INST_GROUPS 7
+#define DFFT_NUM_INST_GROUPS 10
