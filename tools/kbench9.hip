@@ -81,6 +81,30 @@ __global__ void __launch_bounds__(512) tile_copy(const d2* in, d2* out, long lon
     }
 }
 
+// same as tile_copy<RUN=true, nt, prefetch> but every XCD (blockIdx % 8) walks its own contiguous eighth of the tiles
+template <bool NTL, bool NTS>
+__global__ void __launch_bounds__(512) xtile_xcd(const d2* in, d2* out, long long ia, long long istride, long long oa,
+                                                 unsigned ntiles, unsigned tiles_per_a) {
+    const int tid = threadIdx.x, c = tid & 7, j = tid >> 3;
+    const unsigned xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = ntiles / 8, step = gridDim.x >> 3;
+    for (unsigned tl = local; tl < per; tl += step) {
+        const unsigned t = xcd * per + tl;
+        const unsigned a = t / tiles_per_a, b = t - a * tiles_per_a;
+        const d2* ip = in + (long long)a * ia + (long long)b * 8;
+        d2 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ld<NTL>(ip + (long long)(j + 64 * k) * istride + c);
+        d2* op = out + (long long)a * oa + (long long)b * 8 * 512;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st<NTS>(op + tid + 512 * k, v[k]);
+    }
+}
+
+template <int THREADS, bool NTL, bool NTS> __global__ void __launch_bounds__(THREADS) linear_copy_t(const d2* in, d2* out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * THREADS;
+    for (size_t i = (size_t)blockIdx.x * THREADS + threadIdx.x; i < n; i += stride) st<NTS>(out + i, ld<NTL>(in + i));
+}
+
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 7;
     const size_t n = 512ull * 512 * 512;
@@ -99,6 +123,16 @@ int main(int argc, char** argv) {
         cases.push_back({"linear U4 plain      grid " + std::to_string(grid), [=] { linear_copy<4, false, false><<<grid, 512, 0, s>>>(a, b, n); }});
         cases.push_back({"linear U4 nt         grid " + std::to_string(grid), [=] { linear_copy<4, true, true><<<grid, 512, 0, s>>>(a, b, n); }});
         cases.push_back({"linear U8 nt         grid " + std::to_string(grid), [=] { linear_copy<8, true, true><<<grid, 512, 0, s>>>(a, b, n); }});
+    }
+    for (int grid : {128, 256, 384, 512, 768}) {
+        cases.push_back({"linear U1 plain 512thr grid " + std::to_string(grid), [=] { linear_copy_t<512, false, false><<<grid, 512, 0, s>>>(a, b, n); }});
+        cases.push_back({"linear U1 nt    512thr grid " + std::to_string(grid), [=] { linear_copy_t<512, true, true><<<grid, 512, 0, s>>>(a, b, n); }});
+        cases.push_back({"linear U1 plain 256thr grid " + std::to_string(grid * 2), [=] { linear_copy_t<256, false, false><<<grid * 2, 256, 0, s>>>(a, b, n); }});
+        cases.push_back({"linear U1 plain 1024thr grid " + std::to_string(grid / 2), [=] { linear_copy_t<1024, false, false><<<grid / 2, 1024, 0, s>>>(a, b, n); }});
+    }
+    for (int grid : {256, 512, 1024}) {
+        cases.push_back({"xtile xcd-contiguous nt grid " + std::to_string(grid), [=] { xtile_xcd<true, true><<<grid, 512, 0, s>>>(a, b, 512, 512 * 512, 512 * 512, 512 * 64, 64); }});
+        cases.push_back({"xtile xcd-contiguous plain grid " + std::to_string(grid), [=] { xtile_xcd<false, false><<<grid, 512, 0, s>>>(a, b, 512, 512 * 512, 512 * 512, 512 * 64, 64); }});
     }
     cases.push_back({"hipMemcpyAsync DtoD", [=] { CK(hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, s)); }});
     const unsigned nt = 512 * 64;  // 512 `a` slices x 64 column tiles
