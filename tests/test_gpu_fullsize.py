@@ -14,11 +14,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CONFIGS = [
-    pytest.param((256, 256, 256), 1, "f64", id="C2-256^3-fp64-P1"),
-    pytest.param((512, 512, 512), 1, "f64", id="512^3-fp64-P1"),
-    pytest.param((512, 512, 512), 4, "f64", id="C3-512^3-fp64-P4"),
-    pytest.param((1024, 768, 512), 8, "f64", id="C4-1024x768x512-fp64-P8"),
-    pytest.param((2048, 2048, 1024), 8, "f32", id="C5-2048x2048x1024-fp32-P8"),
+    pytest.param((256, 256, 256), 1, "f64", False, id="C2-256^3-fp64-P1"),
+    pytest.param((512, 512, 512), 1, "f64", False, id="512^3-fp64-P1"),
+    pytest.param((512, 512, 512), 4, "f64", False, id="C3-512^3-fp64-P4"),
+    pytest.param((1024, 768, 512), 8, "f64", False, id="C4-1024x768x512-fp64-P8"),
+    pytest.param((2048, 2048, 1024), 8, "f32", False, id="C5-2048x2048x1024-fp32-P8"),
+    # the overlapped pipeline (X-plane parts, Y sub-blocks) at full size -- what bench.py times for P > 1
+    pytest.param((512, 512, 512), 4, "f64", True, id="C3-512^3-fp64-P4-overlap"),
+    pytest.param((512, 512, 512), 8, "f64", True, id="512^3-fp64-P8-overlap"),
+    pytest.param((2048, 2048, 1024), 8, "f32", True, id="C5-2048x2048x1024-fp32-P8-overlap"),
 ]
 TOL = {"f64": 1e-11, "f32": 5e-4}
 
@@ -44,8 +48,8 @@ def _run(plans):
     assert not errs, errs
 
 
-@pytest.mark.parametrize("N,P,prec", CONFIGS)
-def test_fullsize_properties(gpu, N, P, prec):
+@pytest.mark.parametrize("N,P,prec,overlap", CONFIGS)
+def test_fullsize_properties(gpu, N, P, prec, overlap):
     import torch
     from distributedfft_amd import api
     n0, n1, n2 = N
@@ -54,7 +58,7 @@ def test_fullsize_properties(gpu, N, P, prec):
     free, _ = torch.cuda.mem_get_info()
     need = 0
     for g in range(P):
-        need += 3 * api.get_max_data_count(n0, n1, n2, P, g == P - 1) * (16 if prec == "f64" else 8)
+        need += (4 if overlap else 3) * api.get_max_data_count(n0, n1, n2, P, g == P - 1) * (16 if prec == "f64" else 8)
     if need * 1.6 > free:
         pytest.skip(f"needs {need * 1.6 / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} free")
 
@@ -82,7 +86,8 @@ def test_fullsize_properties(gpu, N, P, prec):
         b = torch.zeros(mc, dtype=cdt, device=gpu)
         ins.append(a)
         outs.append(b)
-        plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, api.FORWARD, api.PLAN_INPUT_FROM_IN))
+        plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, api.FORWARD,
+                              api.PLAN_INPUT_FROM_IN | (api.PLAN_OVERLAP if overlap else 0)))
     _run(plans)
 
     # expected: 1 everywhere (impulse) + a_m * N at (kx, ky, kz); layout out_d[yy][z][kx]
