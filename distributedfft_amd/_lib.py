@@ -36,7 +36,7 @@ SIGNATURES = {
     "dfft_local_count": (_LL, [_LLP, C.c_int, C.c_int]),
     "dfft_max_count": (_LL, [_LL, _LL, _LL, C.c_int, C.c_int]),
     "dfft_exchange_layout": (C.c_int, [_LL, _LL, _LL, C.c_int, C.c_int, C.c_int, _LLP, _LLP, _LLP, _LLP]),
-    "dfft_exchange_part_layout": (C.c_int, [_LL, _LL, _LL, C.c_int, C.c_int, _LL, C.c_int, C.c_int, C.c_int, C.c_int,
+    "dfft_exchange_part_layout": (C.c_int, [_LL, _LL, _LL, C.c_int, C.c_int, C.c_int, _LL, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.POINTER(C.c_int), _LLP, _LLP, _LLP, _LLP]),
     "dfft_local_size": (C.c_int, [_LL, _LL, _LL, C.c_int, C.c_int, _LLP, _LLP, _LLP, _LLP]),
     "dfft_comm_create_local": (C.c_int, [C.c_int, C.POINTER(_VP)]),

@@ -57,13 +57,14 @@ def exchange_layout(n0, n1, n2, total_devices: int, global_idx: int, direction: 
 
 
 def exchange_part_layout(n0, n1, n2, total_devices: int, global_idx: int, part_planes: int, part: int, ycuts: int = 1,
-                         ycut: int = -1):
-    """Messages of one piece of the overlapped forward exchange: list of (peer, soffset, scount, roffset, rcount)."""
+                         ycut: int = -1, direction: int = FORWARD):
+    """Messages of one piece of the overlapped exchange: list of (peer, soffset, scount, roffset, rcount)."""
     lib = L.load()
     cap = total_devices * max(1, ycuts)
     peer = (C.c_int * cap)()
     arrs = [(C.c_longlong * cap)() for _ in range(4)]
-    n = lib.dfft_exchange_part_layout(n0, n1, n2, total_devices, global_idx, part_planes, part, ycuts, ycut, cap, peer, *arrs)
+    n = lib.dfft_exchange_part_layout(n0, n1, n2, total_devices, global_idx, direction, part_planes, part, ycuts, ycut, cap,
+                                      peer, *arrs)
     if n < 0:
         L.check(n, "dfft_exchange_part_layout")
     return [(peer[i], arrs[0][i], arrs[1][i], arrs[2][i], arrs[3][i]) for i in range(n)]

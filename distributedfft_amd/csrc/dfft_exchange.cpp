@@ -96,7 +96,55 @@ Round whole_round(const ExchangeDesc& x) {
 
 // Messages of X-plane part k (and Y sub-block `ycut`, or all of them for -1), ordered by peer then sub-block: both ends of
 // a pair enumerate their common messages in the same order, which is what RCCL's send/recv matching needs.
+// Backward exchange (Y slabs -> X slabs), the mirror image: what a forward piece receives is what the backward piece
+// sends, and vice versa.  Send buffer [k][x all][y in k][N2] (the inverse X pass of Y sub-block k writes it), receive
+// buffer [k][src][x mine][y in k][N2] (ycuts = 1: [x all][y mine][N2] and the reference's packed [src][x][y_src][N2]).
+Round part_round_backward(const ExchangeDesc& x, int k, long long cp, int ycut) {
+    Round r;
+    long long mx0, mnx;
+    part_range(x.xsize[x.me], cp, k, &mx0, &mnx);
+    std::vector<long long> xstart(x.P + 1, 0);
+    for (int q = 0; q < x.P; ++q) xstart[q + 1] = xstart[q] + x.xsize[q];
+    if (x.ycuts <= 1) {
+        for (int q = 0; q < x.P; ++q) {
+            long long qx0, qnx;
+            part_range(x.xsize[q], cp, k, &qx0, &qnx);
+            Msg m;
+            m.peer = q;
+            // q's planes [qx0, qx0+qnx) out of my [x all][y mine][N2]
+            m.so = x.soffset[q] + qx0 * x.ysize[x.me] * x.n2;
+            m.sc = qnx * x.ysize[x.me] * x.n2;
+            // where they land at q: block `me` of its packed [src][x of q][y_src][N2]
+            m.doff = x.doffset[q] + qx0 * x.ysize[x.me] * x.n2;
+            // my planes [mx0, mx0+mnx) from q: block q of my packed buffer
+            m.ro = x.roffset[q] + mx0 * x.ysize[q] * x.n2;
+            m.rc = mnx * x.ysize[q] * x.n2;
+            r.push_back(m);
+        }
+        return r;
+    }
+    const int       K = x.ycuts;
+    const long long ysub = x.ysize[0] / K, row = ysub * x.n2, n0 = xstart[x.P];
+    for (int q = 0; q < x.P; ++q) {
+        long long qx0, qnx;
+        part_range(x.xsize[q], cp, k, &qx0, &qnx);
+        for (int y = 0; y < K; ++y) {
+            if (ycut >= 0 && y != ycut) continue;
+            Msg m;
+            m.peer = q;
+            m.so = (long long)y * n0 * row + (xstart[q] + qx0) * row;                  // [y][x global][ysub][N2]
+            m.sc = qnx * row;
+            m.doff = ((long long)y * x.P + x.me) * x.xsize[q] * row + qx0 * row;       // [y][src][x of q][ysub][N2] at q
+            m.ro = ((long long)y * x.P + q) * x.xsize[x.me] * row + mx0 * row;
+            m.rc = mnx * row;
+            r.push_back(m);
+        }
+    }
+    return r;
+}
+
 Round part_round(const ExchangeDesc& x, int k, long long cp, int ycut) {
+    if (x.direction == DFFT_BACKWARD) return part_round_backward(x, k, cp, ycut);
     Round r;
     long long mx0, mnx;
     part_range(x.xsize[x.me], cp, k, &mx0, &mnx);

@@ -40,6 +40,7 @@ int get_twiddles(int n, int dtype, const void** table);
 struct ExchangeDesc {
     int                    dtype;
     int                    P, me;
+    int                    direction = DFFT_FORWARD;  // X -> Y slabs (forward) or Y -> X slabs (backward)
     int                    slot = 0;  // 0 forward, 1 backward: which registered receive buffer of the peers to push into
     void*                  sendbuf;  // bufferDev2
     void*                  recvbuf;  // bufferDev1 (this device's; peers' are looked up through the communicator)

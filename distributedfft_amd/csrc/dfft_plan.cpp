@@ -173,6 +173,7 @@ static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
     const int       P = p->P, me = p->me;
     const long long n2 = p->N[2];
     x.dtype = p->dtype;
+    x.direction = direction;
     x.P = P;
     x.me = me;
     x.scount.assign(P, 0);
@@ -485,6 +486,50 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     StageClock      clk{p, sync};
     DFFT_TRY(clk.begin());
     const void* src = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
+    if (fused && p->exch && (p->flags & DFFT_PLAN_OVERLAP) && p->part_planes > 0) {
+        // ---- mirror image of the overlapped forward pipeline: the inverse X pass runs Y sub-block by sub-block into the
+        // send buffer [k][x all][y in k][N2] and sub-block k is exchanged (stream2) while sub-block k+1 is transformed;
+        // the last sub-block is exchanged X-plane part by part, and the Y+Z passes of part i start when part i has landed.
+        const bool      rccl = comm_kind(p->comm) == 1;
+        const int       I = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
+        const int       YK = p->ycuts;
+        const long long ysub = p->ys / YK;
+        const size_t    sub = (size_t)n0 * ysub * n2 * elem_bytes(p->dtype);
+        hipStream_t     xs_ = rccl ? p->stream2 : p->stream;  // LOCAL: host-synchronising, same call sequence
+        for (int y = 0; y < YK; ++y) {
+            if (YK == 1) DFFT_TRY(launch_x(p, src, p->rbuf));
+            else DFFT_TRY(launch_x(p, (const char*)src + y * sub, (char*)p->rbuf + y * sub, false, ysub));
+            if (rccl) {
+                hipEvent_t done = YK == 1 ? p->join_ev : p->y_ev[y];
+                DFFT_HIP_TRY(hipEventRecord(done, p->stream));
+                DFFT_HIP_TRY(hipStreamWaitEvent(p->stream2, done, 0));
+            }
+            if (y + 1 < YK) {
+                DFFT_TRY(comm_exchange_part(p->comm, p->xd, 0, p->sx.blk, xs_, y));  // all X planes of sub-block y
+            } else {
+                for (int i = 0; i < I; ++i) {
+                    DFFT_TRY(comm_exchange_part(p->comm, p->xd, i, p->part_planes, xs_, YK == 1 ? -1 : y));
+                    if (rccl) DFFT_HIP_TRY(hipEventRecord(p->part_ev[i], p->stream2));
+                }
+            }
+        }
+        DFFT_TRY(clk.end_stage());  // inverse X passes (the exchange of the earlier sub-blocks runs underneath)
+        for (int i = 0; i < I; ++i) {
+            if (rccl) DFFT_HIP_TRY(hipStreamWaitEvent(p->stream, p->part_ev[i], 0));
+            if (i == 0) {
+                DFFT_TRY(clk.end_stage());  // exposed part of the exchange
+                DFFT_TRY(clk.end_stage());  // unpack folded into the Y pass
+            }
+            long long x0, nx;
+            part_range(p->xs, p->part_planes, i, &x0, &nx);
+            if (nx > 0) {
+                DFFT_TRY(launch_y(p, p->buf1, p->buf2, false, true, x0, nx, FFT_HINT_STREAM_IN));
+                DFFT_TRY(fft_rows(p->buf2, p->buf2, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1));
+            }
+        }
+        DFFT_TRY(clk.end_stage());
+        return DFFT_OK;
+    }
     // ---- inverse X FFT: [ys][N2][kx] -> [x][ys][N2] ----
     if (fused) {
         DFFT_TRY(launch_x(p, src, p->buf2));
@@ -616,11 +661,11 @@ int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_dev
     return DFFT_OK;
 }
 
-int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long part_planes,
-                              int part, int ycuts, int ycut, int max_msgs, int* peer, long long* soffset, long long* scount,
-                              long long* roffset, long long* rcount) {
+int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
+                              long long part_planes, int part, int ycuts, int ycut, int max_msgs, int* peer,
+                              long long* soffset, long long* scount, long long* roffset, long long* rcount) {
     if (total_devices < 1 || global_idx < 0 || global_idx >= total_devices || part_planes < 1 || part < 0 || ycuts < 1 ||
-        ycut >= ycuts || max_msgs < 0)
+        ycut >= ycuts || max_msgs < 0 || (direction != DFFT_FORWARD && direction != DFFT_BACKWARD))
         return fail(DFFT_EINVAL, "dfft_exchange_part_layout: bad arguments");
     if (ycuts > 1 && (n0 % total_devices != 0 || n1 % total_devices != 0 || (n1 / total_devices) % ycuts != 0))
         return fail(DFFT_EINVAL, "dfft_exchange_part_layout: Y sub-blocks need even X and Y splits divisible by ycuts");
@@ -630,13 +675,13 @@ int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int tota
     tmp.N[2] = n2;
     tmp.P = total_devices;
     tmp.me = global_idx;
-    tmp.direction = DFFT_FORWARD;
+    tmp.direction = direction;
     tmp.dtype = DFFT_F64;
     tmp.sx = make_slab(n0, total_devices);
     tmp.sy = make_slab(n1, total_devices);
     if (tmp.sx.size(total_devices - 1) < 1 || tmp.sy.size(total_devices - 1) < 1)
         return fail(DFFT_EINVAL, "dfft_exchange_part_layout: last slab would be empty");
-    fill_exchange(&tmp, tmp.xd, DFFT_FORWARD);
+    fill_exchange(&tmp, tmp.xd, direction);
     tmp.xd.ycuts = ycuts;
     std::vector<int>       pe;
     std::vector<long long> so, sc, ro, rc;
@@ -773,8 +818,10 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
-    if ((flags & DFFT_PLAN_OVERLAP) && p->exch && direction == DFFT_FORWARD &&
-        !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL))) {
+    // forward: always; backward: out-of-place plans that read the caller's `in` (the inverse X pass of sub-block k+1 must
+    // not read a buffer the exchange of sub-block k is receiving into)
+    if ((flags & DFFT_PLAN_OVERLAP) && p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) &&
+        (direction == DFFT_FORWARD || (flags & DFFT_PLAN_INPUT_FROM_IN))) {
         // parts: DFFT_OVERLAP_PARTS (default 4) per slab, never larger than one Infinity-Cache chunk; derived from the
         // global block size ceil(N0/P) so that every rank cuts identically
         long long   parts = 4;
@@ -838,7 +885,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             dfft_plan_destroy(p);
             return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
         }
-        p->xd.recvbuf = p->rbuf;
+        if (direction == DFFT_FORWARD) p->xd.recvbuf = p->rbuf;  // Y pass -> out (send) -> rbuf (receive) -> X pass -> out
+        else p->xd.sendbuf = p->rbuf;                            // in -> X pass -> rbuf (send) -> bufferDev1 -> Y,Z -> out
         p->xd.ycuts = p->ycuts;
     }
     if (comm) {

@@ -48,7 +48,9 @@ extern "C" {
                                        in t3.  Default is fused (pack and transpose folded into the FFT kernels' stores). */
 #define DFFT_PLAN_INPUT_FROM_IN 2u  /* every execute re-reads the caller's `in` (first pass runs out-of-place in -> bufferDev1)
                                        instead of consuming bufferDev1; out-of-place plans only.  Same HBM traffic. */
-#define DFFT_PLAN_OVERLAP 4u        /* forward, P > 1: exchange in X-plane parts on a second stream, overlapped with t0 */
+#define DFFT_PLAN_OVERLAP 4u        /* P > 1: the exchange runs in pieces on a second stream -- X-plane parts overlapped with
+                                       the YZ stage, Y sub-blocks with the X stage (forward plans; backward plans that also
+                                       set DFFT_PLAN_INPUT_FROM_IN).  Results are bit-identical to the serial pipeline. */
 #define DFFT_PLAN_NATURAL 8u        /* input AND output in the natural X-slab layout [x_local][N1][N2] (both directions):
                                        the un-transposed output the reference declares (fft_mpi_local_size_3d,
                                        fft_mpi_3d_api.h:73) but never implements.  Costs a second all-to-all when P > 1. */
@@ -66,7 +68,8 @@ const char* dfft_version(void);
 const char* dfft_last_error(void);
 /* Number of visible HIP devices (0 if none).  hipGetDeviceCount in fftSpeed3d_c2c.cpp:33-34. */
 int dfft_device_count(void);
-/* 1 if FFT length n has a compiled gfx950 plan (radix 2/3/4/5/8 products listed in csrc/dfft_plans.h). */
+/* 1 if FFT length n is supported: any product of 2, 3, 5, 7 up to 4096 (tuned plans for the lengths listed in
+ * csrc/dfft_plans.h, a run-time-scheduled kernel for the rest) -- the single-pass range of the reference's generator. */
 int dfft_length_supported(long long n);
 
 /* ---- slab bookkeeping: pure host arithmetic, callable without a GPU ------------------------------------------------ */
@@ -82,15 +85,16 @@ long long dfft_max_count(long long n0, long long n1, long long n2, int total_dev
  * Arrays have total_devices entries.  direction = DFFT_FORWARD or DFFT_BACKWARD. */
 int dfft_exchange_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
                          long long* scount, long long* soffset, long long* rcount, long long* roffset);
-/* The messages of ONE piece of the overlapped forward exchange (DFFT_PLAN_OVERLAP) as device global_idx issues them:
- * X-plane part `part` when every device cuts its slab into parts of `part_planes` planes, restricted to Y sub-block `ycut`
- * of `ycuts` (or all sub-blocks for ycut = -1).  Message m goes to / comes from peer[m]; offsets/counts in elements of the
- * send buffer (packed [k][dst][x][y in k][N2]; [dst][x][y][N2] for ycuts = 1) and the receive buffer ([k][x][y in k][N2]).
+/* The messages of ONE piece of the overlapped exchange (DFFT_PLAN_OVERLAP) as device global_idx issues them: X-plane part
+ * `part` when every device cuts its X slab into parts of `part_planes` planes, restricted to Y sub-block `ycut` of `ycuts`
+ * (or all sub-blocks for ycut = -1).  Message m goes to / comes from peer[m]; offsets/counts in elements.
+ *   forward : send buffer packed [k][dst][x][y in k][N2] ([dst][x][y][N2] for ycuts = 1), receive buffer [k][x][y in k][N2]
+ *   backward: the mirror image -- send buffer [k][x][y in k][N2], receive buffer [k][src][x][y in k][N2]
  * Both ends enumerate the messages of a pair in the same order.  Returns the number of messages, or a negative error.
  * (Refines slabAlltoall's per-peer chunks, fft_mpi_3d_api.cpp:610-672, into the pieces the pipeline overlaps.) */
-int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long part_planes,
-                              int part, int ycuts, int ycut, int max_msgs, int* peer, long long* soffset, long long* scount,
-                              long long* roffset, long long* rcount);
+int dfft_exchange_part_layout(long long n0, long long n1, long long n2, int total_devices, int global_idx, int direction,
+                              long long part_planes, int part, int ycuts, int ycut, int max_msgs, int* peer,
+                              long long* soffset, long long* scount, long long* roffset, long long* rcount);
 /* local extents: x planes owned before / y rows owned after the forward transform, and their global starts.
  * (the declared-but-never-defined fft_mpi_local_size_3d, fft_mpi_3d_api.h:73) */
 int dfft_local_size(long long n0, long long n1, long long n2, int total_devices, int global_idx, long long* local_n0,

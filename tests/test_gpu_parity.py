@@ -248,6 +248,14 @@ def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, yparts, monkeypa
     outs2, _ = _run_plans(gpu, N, P, "f64", x, +1, api.PLAN_OVERLAP | api.PLAN_INPUT_FROM_IN, inputs)
     for d in range(P):
         assert np.array_equal(outs2[d][:ref[d].size], outs[d][:ref[d].size])
+    # backward: the mirror pipeline (inverse X pass per Y sub-block || exchange, Y+Z per X-plane part as it lands) must
+    # reproduce the serial backward transform bit for bit and return N x
+    serial, _ = _run_plans(gpu, N, P, "f64", None, -1, api.PLAN_INPUT_FROM_IN, [r for r in ref])
+    over, _ = _run_plans(gpu, N, P, "f64", None, -1, api.PLAN_OVERLAP | api.PLAN_INPUT_FROM_IN, [r for r in ref])
+    for g in range(P):
+        cnt = inputs[g].size
+        assert np.array_equal(over[g][:cnt], serial[g][:cnt]), f"backward overlap N={N} P={P} dev={g}"
+        assert np.abs(over[g][:cnt].reshape(inputs[g].shape) / float(n0 * n1 * n2) - inputs[g]).max() < 1e-10
 
 
 def test_in_place_plans_and_reload(gpu):
@@ -356,8 +364,9 @@ for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP,
     out, t = run(x, api.FORWARD, flags)
     assert np.abs(out.reshape(tr.shape) - tr).max() / scale < 1e-11, flags
     assert t[2] > 0 or flags & api.PLAN_OVERLAP, (flags, t)   # the exchange stage really ran
-out, _ = run(tr, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
-assert np.abs(out.reshape(N) / x.size - x).max() < 1e-11
+for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP):
+    out, _ = run(tr, api.BACKWARD, flags)
+    assert np.abs(out.reshape(N) / x.size - x).max() < 1e-11, flags
 out, _ = run(x, api.FORWARD, api.PLAN_INPUT_FROM_IN | api.PLAN_NATURAL)
 assert np.abs(out.reshape(N) - ref).max() / scale < 1e-11
 out, _ = run(ref, api.BACKWARD, api.PLAN_INPUT_FROM_IN | api.PLAN_NATURAL)

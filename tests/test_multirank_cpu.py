@@ -127,8 +127,40 @@ if YK > 1:
 else:
     want = ref.reshape(-1)
 err = float(np.abs(got - want).max())
-t = torch.tensor([err]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-if rank == 0: print("RESULT", t[0].item())
+
+# ---- and back: the mirror pieces (Y sub-blocks whole, the last one X-plane part by part) return every rank's X slab ----
+bsend = got.copy()                                                   # [k][x all][y in k][N2] ([x][ys][N2] for YK = 1)
+brecv = np.full(recv.size, np.nan + 0j, dtype=np.complex128)
+blk = so.slab_size(n0, world, 0)
+bmoved = 0
+for y in range(YK):
+    last = (y + 1 == YK)
+    for part in (range(nparts) if last else [0]):
+        msgs = api.exchange_part_layout(n0, n1, n2, world, rank, PP if last else blk, part, YK, y if YK > 1 else -1, api.BACKWARD)
+        ops, bufs = [], []
+        for peer, so_, sc, ro, rc in msgs:
+            if peer == rank:
+                assert sc == rc
+                brecv[ro:ro + rc] = bsend[so_:so_ + sc]; bmoved += sc
+                continue
+            if sc:
+                t = torch.from_numpy(bsend[so_:so_ + sc].view(np.float64).copy()); ops.append(dist.P2POp(dist.isend, t, peer)); bmoved += sc
+            if rc:
+                r = torch.empty(2 * rc, dtype=torch.float64); ops.append(dist.P2POp(dist.irecv, r, peer)); bufs.append((ro, rc, r))
+        if ops:
+            for w in dist.batch_isend_irecv(ops): w.wait()
+        for ro, rc, r in bufs:
+            brecv[ro:ro + rc] = r.numpy().view(np.complex128)
+assert bmoved == n0 * ys * n2, (bmoved, n0 * ys * n2)
+# what arrived is this rank's planes of the YZ-transformed array in the packed layout the forward pipeline sent
+if YK > 1:
+    back = brecv[:send.size]
+    berr = float(np.abs(back - send).max())
+else:
+    lay = api.exchange_layout(n0, n1, n2, world, rank, api.FORWARD)
+    berr = max(float(np.abs(brecv[o:o + c] - send[o:o + c]).max()) for o, c in zip(lay.soffset, lay.scount) if c)
+t = torch.tensor([err, berr]); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0: print("RESULT", t[0].item(), t[1].item())
 dist.destroy_process_group()
 '''
 
@@ -150,7 +182,7 @@ def test_gloo_overlapped_exchange_pieces(native_lib, N, world, part_planes, ycut
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-2500:]
     line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
-    assert float(line[1]) < 1e-11
+    assert float(line[1]) < 1e-11 and float(line[2]) == 0.0   # forward pieces; backward pieces return the sent data exactly
 
 
 BOOT_WORKER = r'''
