@@ -351,8 +351,11 @@ def run(data, direction, flags):
     b = torch.zeros_like(a)
     torch.cuda.synchronize()
     p = api.Plan(*N, a, b, comm, 0, 1, direction, flags)
-    for _ in range(2):
-        p.execute()
+    p.execute(api.EXEC_SYNC_STAGES)       # host-timed stages (the driver's mode), then the asynchronous mode
+    p.sync()
+    ts = p.stage_times()
+    assert all(v >= 0 for v in ts)
+    p.execute()
     p.sync()
     t = p.stage_times()
     out = b.cpu().numpy()
