@@ -194,7 +194,10 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
 //   TW_GLOBAL N-entry table read through L1/L2 (only when the LDS is needed for the exchange tile, e.g. N = 2048)
 enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 
-template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW>
+// PH = 2: the tile (N x CB elements) is twice what the LDS holds, so every exchange runs in two phases -- first the threads
+// of columns [0, CB/2), then those of [CB/2, CB) -- through one half-size buffer.  HBM accesses keep full 128-byte lines
+// (all CB columns of a row segment are loaded/stored together); only the LDS issue slots double.
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW, int PH = 1>
 __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W* twr, V* lds, int j, int c) {
     using SI = StageInfo<P, S, TWPOW>;
     using W = typename VecTraits<V>::W;
@@ -241,21 +244,45 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
     if constexpr (S + 1 < P::S) {
 #ifdef DFFT_DBG_NOEXCH
         // measurement builds only (tools/kbench): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH>(v, twr, lds, j, c);
         return;
 #endif
-        if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
+        if constexpr (PH == 1) {
+            if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
 #pragma unroll
-        for (int q = 0; q < B; ++q) {
-            const int jq = j + q * T;
-            const int base = (jq / NS) * (NS * R) + (jq % NS);
+            for (int q = 0; q < B; ++q) {
+                const int jq = j + q * T;
+                const int base = (jq / NS) * (NS * R) + (jq % NS);
 #pragma unroll
-            for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
+                for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
+            }
+            group_sync<WAVE_LOCAL>();
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
+        } else {
+            static_assert(PH == 1 || (!PAD && !WAVE_LOCAL && CB % PH == 0), "two-phase exchange: block-wide column tiles");
+            constexpr int CH = CB / PH;
+            const int     mine = c / CH, cl = c - mine * CH;
+#pragma unroll
+            for (int ph = 0; ph < PH; ++ph) {
+                __syncthreads();  // WAR: the readers of the previous phase / stage are done
+                if (mine == ph) {
+#pragma unroll
+                    for (int q = 0; q < B; ++q) {
+                        const int jq = j + q * T;
+                        const int base = (jq / NS) * (NS * R) + (jq % NS);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) lds[(base + r * NS) * CH + cl] = v[q + r * B];
+                    }
+                }
+                __syncthreads();
+                if (mine == ph) {
+#pragma unroll
+                    for (int k = 0; k < E; ++k) v[k] = lds[(j + T * k) * CH + cl];
+                }
+            }
         }
-        group_sync<WAVE_LOCAL>();
-#pragma unroll
-        for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH>(v, twr, lds, j, c);
     }
 }
 
@@ -267,11 +294,15 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     static constexpr bool OSTAGE = Tune::OSTAGE && CB > 1 && P::S > 1;
     // exchange tile; the staged store needs [CB][N + 1] (one pad element per column keeps the transposed writes on
     // distinct banks)
-    static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB : 0;
+    // a tile above 128 KiB (1280-, 1536-, 2048-point full-line column tiles) goes through the LDS in two phases of CB/2
+    // columns each (run_stages): full 128-byte lines on the HBM side without a 256 KiB exchange buffer
+    static constexpr int PH = (P::S > 1 && CB > 1 && (size_t)P::N * CB * sizeof(V) > 128 * 1024) ? 2 : 1;
+    static_assert(CB % PH == 0 && P::E % PH == 0, "two-phase tiles need an even column count and an even E");
+    static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB / PH : 0;
     // staged image: one scalar column per row of N + OPAD twiddle-typed elements (OPAD = 2 keeps cpair rows 16-B aligned)
     static constexpr int LANES = VecTraits<V>::LANES;
     static constexpr int OPAD = LANES == 2 ? 2 : 1;
-    static constexpr int OS_ELEMS = OSTAGE ? (P::N + OPAD) * CB : 0;  // in units of V (= LANES scalar elements)
+    static constexpr int OS_ELEMS = OSTAGE ? (P::N + OPAD) * CB / PH : 0;  // in units of V (= LANES scalar elements)
     static_assert(!OSTAGE || P::N % LANES == 0, "the staged store of column pairs needs an even length");
     static constexpr int LDS_ELEMS = EX_ELEMS > OS_ELEMS ? EX_ELEMS : OS_ELEMS;
     static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
@@ -390,8 +421,11 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
         // staged store: thread owns the linear memory elements tid + GT*k of the [CB*LANES scalar columns][ON] result
         // tile (omap.cstride is then the distance between SCALAR columns, omap.stride the one between memory elements)
-        const int oc = KG::OSTAGE ? (tid + GT * k) / ON : c;
-        const int oidx = KG::OSTAGE ? (tid + GT * k) % ON : idx;
+        // (two-phase tiles: points [0, E/2) belong to the image of columns [0, CB/2), the rest to the second image)
+        constexpr int EPH = E / KG::PH;
+        const int lin_o = tid + GT * (k % EPH);
+        const int oc = KG::OSTAGE ? (k / EPH) * (CB / KG::PH) * LANES + lin_o / ON : c;
+        const int oidx = KG::OSTAGE ? lin_o % ON : idx;
         const int ob = oidx / omap.blk;
         orel[k] = (unsigned)(block_term(omap, ob) + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
         if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
@@ -442,13 +476,11 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             load_tile(t0, v);
         }
 
-        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW>(v, twr, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW, KG::PH>(v, twr, lds, j, c);
 
-        if (scale != 1.0) {  // normalisation folded into this pass (uniform branch; plans set it on the X pass only)
-            const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
-#pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = cscale(v[k], sc);
-        }
+        // normalisation folded into this pass: every result is multiplied on its way out (x * 1.0 is exact, so the default
+        // changes nothing; a branch around a separate scaling loop cost 15 VGPRs and made the 16-point kernels spill)
+        const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
 
         if constexpr (KG::OSTAGE) {
             // results (column c, idx = j + T*k) -> LDS [scalar column][N + OPAD] -> linear order, so a wave stores
@@ -456,18 +488,43 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             static_assert(!GENERAL || !KG::OSTAGE, "the staged store is a fast-path variant");
             constexpr int ROW = N + KG::OPAD;
             W* img = reinterpret_cast<W*>(lds);
-            group_sync<KG::WAVE_LOCAL>();
+            if constexpr (KG::PH == 1) {
+                group_sync<KG::WAVE_LOCAL>();
 #pragma unroll
-            for (int k = 0; k < E; ++k)
+                for (int k = 0; k < E; ++k)
 #pragma unroll
-                for (int l = 0; l < LANES; ++l) img[(c * LANES + l) * ROW + j + T * k] = VT::lane(v[k], l);
-            group_sync<KG::WAVE_LOCAL>();
-            if (valid) {
+                    for (int l = 0; l < LANES; ++l) img[(c * LANES + l) * ROW + j + T * k] = VT::lane(cscale(v[k], sc), l);
+                group_sync<KG::WAVE_LOCAL>();
+                if (valid) {
 #pragma unroll
-                for (int k = 0; k < E; ++k) {
-                    const int lin = tid + GT * k;
-                    const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
-                    gstore<Tune::NTS>(op + (long long)orel[PLAIN ? 0 : k], r);
+                    for (int k = 0; k < E; ++k) {
+                        const int lin = tid + GT * k;
+                        const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
+                        gstore<Tune::NTS>(op + (long long)orel[PLAIN ? 0 : k], r);
+                    }
+                }
+            } else {
+                // two images of CB/2 columns each through the same buffer; every thread stores E/2 elements per image
+                constexpr int CH = CB / KG::PH, EPH = E / KG::PH;
+                const int     mine = c / CH, cl = c - mine * CH;
+#pragma unroll
+                for (int ph = 0; ph < KG::PH; ++ph) {
+                    __syncthreads();
+                    if (mine == ph) {
+#pragma unroll
+                        for (int k = 0; k < E; ++k)
+#pragma unroll
+                            for (int l = 0; l < LANES; ++l) img[(cl * LANES + l) * ROW + j + T * k] = VT::lane(cscale(v[k], sc), l);
+                    }
+                    __syncthreads();
+                    if (valid) {
+#pragma unroll
+                        for (int k = 0; k < EPH; ++k) {
+                            const int lin = tid + GT * k;
+                            const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
+                            gstore<Tune::NTS>(op + (long long)orel[ph * EPH + k], r);
+                        }
+                    }
                 }
             }
         } else if (valid) {
@@ -475,7 +532,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
-                gstore<Tune::NTS>(op + off, VT::to_g(v[k]));
+                gstore<Tune::NTS>(op + off, VT::to_g(cscale(v[k], sc)));
             }
         }
         if constexpr (PREFETCH) {
@@ -555,11 +612,20 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
 
 template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };
 
-// Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex) unless the
-// tile would exceed 128 KiB of LDS or 1024 threads, then halve (2048-point fp64 -> 4 columns).
+// Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex).  Tiles up to
+// 128 KiB exchange through the LDS in one go (blocks up to 1024 threads); tiles up to 256 KiB in two phases
+// (KernelGeom::PH) when the block stays at 512 threads and a thread's points fit 96 VGPRs, so that the kernel keeps the
+// 256-register budget without spilling (1280 and 1536 points: 2.9 -> 3.2, 3.2 -> 3.6 TB/s; 2048 points with 32 points per
+// thread spills 190 registers and drops from 3.1 to 2.3 TB/s, so it keeps half-line tiles).  Otherwise halve.
 template <class V, class P> constexpr int cols_per_tile() {
     int cb = 128 / (int)sizeof(V);
-    while (cb > 1 && ((long long)P::N * cb * (long long)sizeof(V) > 128 * 1024 || cb * P::T > 1024)) cb /= 2;
+    constexpr bool two_phase_ok = P::E % 2 == 0 && P::E * (int)sizeof(V) / 4 <= 96;
+    while (cb > 1) {
+        const long long bytes = (long long)P::N * cb * (long long)sizeof(V);
+        const bool      fits = bytes <= 128 * 1024 ? cb * P::T <= 1024 : (two_phase_ok && bytes <= 256 * 1024 && cb * P::T <= 512);
+        if (fits) break;
+        cb /= 2;
+    }
     return cb;
 }
 
@@ -570,35 +636,37 @@ template <class V, class P> constexpr bool can_stage_store() {
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;
     constexpr int L = VecTraits<V>::LANES;
     // (column pairs also stage with half-line tiles: their alternative is the scalar float2 kernel, 2048-point X pass)
+    constexpr int PH = (size_t)P::N * CBC * sizeof(V) > 128 * 1024 ? 2 : 1;  // KernelGeom::PH
     return P::S > 1 && CBC * (int)sizeof(V) >= (L == 2 ? 64 : 128) && P::N % L == 0 &&
-           (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC * GC * sizeof(V) <= 144 * 1024;
+           (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC / PH * GC * sizeof(V) <= 144 * 1024;
 }
 
 // Column launches describe the work as `na` slices of `ncols` columns; the tile geometry follows from the variant's CB.
-template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
-    constexpr int CBC = cols_per_tile<V, P>();
-    constexpr int GR = ConstMax1<256 / P::T>::value;          // row kernel: ~256 threads per block
-    constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
-    FftLaunch L = Lin;
-    if (L.cols) {
-        L.tiles_per_a = (L.ncols + CBC - 1) / CBC;
-        L.ntiles = L.na * L.tiles_per_a;
-    }
+// Row launches (contiguous FFTs, one per tile) may use a plan of their own: the row kernel keeps no column tile in LDS, so
+// it can afford more points per thread than the column kernel of the same length (2048: 32 points, one wave per FFT).
+template <class V, class P> hipError_t launch_rows(const FftLaunch& L, hipStream_t stream) {
+    static_assert(VecTraits<V>::LANES == 1, "column pairs exist only for the column kernel");
+    constexpr int GR = ConstMax1<256 / P::T>::value;  // ~256 threads per block
     if (L.ntiles <= 0) return hipSuccess;
     if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
-    const bool general = L.cols && ((L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0);
-    if (!L.cols) {
-        if constexpr (VecTraits<V>::LANES == 1) {
-            if (L.hints & FFT_HINT_STREAM_IN) {
-                if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
-                return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
-            }
-            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
-            return launch_variant<V, P, 1, GR, -1, false>(L, stream);
-        } else {
-            return hipErrorInvalidValue;  // column pairs exist only for the column kernel
-        }
+    if (L.hints & FFT_HINT_STREAM_IN) {
+        if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
+        return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
     }
+    if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false>(L, stream);
+    return launch_variant<V, P, 1, GR, -1, false>(L, stream);
+}
+
+template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
+    constexpr int CBC = cols_per_tile<V, P>();
+    constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
+    if (!Lin.cols) return hipErrorInvalidValue;  // rows: launch_rows
+    FftLaunch L = Lin;
+    L.tiles_per_a = (L.ncols + CBC - 1) / CBC;
+    L.ntiles = L.na * L.tiles_per_a;
+    if (L.ntiles <= 0) return hipSuccess;
+    if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    const bool general = (L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0;
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
