@@ -155,3 +155,18 @@ def test_driver_cli_argument_check(native_lib):
     assert "ready for attach" in r.stdout
     sh = (ROOT / "speedTest.sh").read_text()
     assert "distFFTOpt" in sh and "$2 $3 $4 1" in sh  # speedTest.sh:6 shape: <ranks> X Y Z -> ./distFFTOpt X Y Z 1
+
+
+def test_headline_kernels_do_not_spill():
+    """The 512-point kernels of the benchmarked path (fp64, and fp32 on column pairs) must compile for gfx950 without
+    scratch: a few extra live registers in the shared kernel template are enough to make the register-heavy variants spill,
+    which costs 20 % long before any parity test notices (tools/kernel_resources.py cross-compiles one instantiation group)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", ROOT / "tools" / "kernel_resources.py")
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    rows = [r for r in kr.kernel_table(3) if " N=512 " in r[0] and (r[0].startswith("f64") or r[0].startswith("pair"))]
+    assert len(rows) >= 20
+    for tag, vgpr, scratch, _ in rows:
+        assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
+        assert vgpr <= 256, f"{tag}: {vgpr} registers (a 512-thread block has 256 per wave)"

@@ -1,0 +1,52 @@
+"""Register / scratch / LDS usage of the FFT kernels of one instantiation group (no GPU needed): compiles
+csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* directives of every fft_tiles_kernel.
+
+  python tools/kernel_resources.py <group> [filter]        e.g.  python tools/kernel_resources.py 3 N=512
+
+A kernel that spills (scratch > 0) or loses occupancy shows up here long before it shows up in a benchmark: the 16- and
+24-point-per-thread column kernels sit within a few registers of the 256-VGPR budget of a 512-thread block."""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "distributedfft_amd" / "csrc"
+
+TYPES = {"15HIP_vector_typeIdLj2EE": "f64", "15HIP_vector_typeIfLj2EE": "f32", "NS_5cpairE": "pair"}
+
+
+def kernel_table(group: int):
+    """[(tag, vgprs incl. AGPRs, scratch bytes, static LDS bytes)] for instantiation group `group`."""
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+               f"-DDFFT_INST_GROUP={group}", "-c", str(CSRC / "dfft_fft_inst.hip"), "-o", "inst.o", "-save-temps"]
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-3000:])
+        asm = next(Path(tmp).glob("*gfx950.s")).read_text()
+    rows = []
+    for m in re.finditer(r"^(_ZN4dfft16fft_tiles_kernel\w+): ", asm, re.M):
+        name = m.group(1)
+        body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
+        mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)EEEv", name)
+        if not mm:
+            continue
+        ty = TYPES.get(mm.group(1), mm.group(1))
+        tag = (f"{ty} N={mm.group(2)} E={mm.group(3)} CB={mm.group(4)} G={mm.group(5)} dir={'-1' if mm.group(6) == 'n1' else '1'} "
+               f"general={mm.group(7)} {mm.group(8)}")
+
+        def field(key):
+            f = re.search(rf"\.amdhsa_{key} (\d+)", body)
+            return int(f.group(1)) if f else 0
+        rows.append((tag, field("next_free_vgpr"), field("private_segment_fixed_size"), field("group_segment_fixed_size")))
+    return rows
+
+
+if __name__ == "__main__":
+    g = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    flt = sys.argv[2] if len(sys.argv) > 2 else ""
+    for tag, vgpr, scratch, lds in kernel_table(g):
+        if flt in tag:
+            print(f"{tag:<70} vgpr {vgpr:>3}  scratch {scratch:>4} B")
