@@ -19,7 +19,7 @@ FORWARD, BACKWARD = 1, -1
 ALLOC_HOST, ALLOC_DEV = 1, -1
 F64, F32 = 0, 1
 PLAN_DEFAULT, PLAN_UNFUSED, PLAN_INPUT_FROM_IN, PLAN_OVERLAP, PLAN_NATURAL = 0, 1, 2, 4, 8
-EXEC_ASYNC, EXEC_SYNC_STAGES, EXEC_PRINT = 0, 1, 2
+EXEC_ASYNC, EXEC_SYNC_STAGES, EXEC_PRINT, EXEC_NO_TIMING = 0, 1, 2, 4
 OK, EINVAL, EHIP, ERCCL, ENOGPU, ECOMM, EUNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 
 _LL = C.c_longlong

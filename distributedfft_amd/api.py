@@ -12,7 +12,7 @@ from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 from . import _lib as L
-from ._lib import (BACKWARD, EXEC_ASYNC, EXEC_PRINT, EXEC_SYNC_STAGES, F32, F64, FORWARD, PLAN_DEFAULT,  # noqa: F401
+from ._lib import (BACKWARD, EXEC_ASYNC, EXEC_NO_TIMING, EXEC_PRINT, EXEC_SYNC_STAGES, F32, F64, FORWARD, PLAN_DEFAULT,  # noqa: F401
                    PLAN_INPUT_FROM_IN, PLAN_NATURAL, PLAN_OVERLAP, PLAN_UNFUSED, DfftError)
 
 

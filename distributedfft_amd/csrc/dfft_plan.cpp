@@ -154,6 +154,7 @@ struct dfft_plan_s {
     hipEvent_t  ev[6];  // [0..4] stage boundaries, [5] between the two FFT kernels of the YZ stage
     double      host_t[4];
     bool        host_timed;
+    bool        timed = true;  // the last execute recorded its stage events (false: DFFT_EXEC_NO_TIMING)
     ExchangeDesc xd;
     ExchangeDesc xd2;        // DFFT_PLAN_NATURAL: the second (Y -> X) exchange
     long long   chunk_planes;  // planes per Z+Y chunk (Infinity-Cache blocking); 0 = whole slab in one launch pair
@@ -314,7 +315,7 @@ struct StageClock {
         if (sync) {
             DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
             t = std::chrono::steady_clock::now();
-        } else {
+        } else if (p->timed) {
             DFFT_HIP_TRY(hipEventRecord(p->ev[0], p->stream));
         }
         return DFFT_OK;
@@ -325,7 +326,7 @@ struct StageClock {
             auto now = std::chrono::steady_clock::now();
             p->host_t[idx] = std::chrono::duration<double>(now - t).count();
             t = now;
-        } else {
+        } else if (p->timed) {
             DFFT_HIP_TRY(hipEventRecord(p->ev[idx + 1], p->stream));
         }
         ++idx;
@@ -409,7 +410,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                           (chunked && zsrc != p->buf1) ? FFT_HINT_STREAM_IN : 0));
-        if (!sync && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
+        if (!sync && p->timed && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
         if (y_packs) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, chunked ? FFT_HINT_STREAM_OUT : 0));  // Y FFT + pack in one pass
         else DFFT_TRY(launch_y(p, p->buf1, p->buf1, true, false, x0, nx));
     }
@@ -565,7 +566,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
         const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0));
         else DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false, x0, nx));
-        if (!sync && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
+        if (!sync && p->timed && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
         DFFT_TRY(fft_rows(ybuf, ybuf, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1));
     }
     DFFT_TRY(clk.end_stage());
@@ -923,6 +924,8 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_execute: null plan");
     const bool sync = (exec_flags & DFFT_EXEC_SYNC_STAGES) != 0;
     plan->host_timed = sync;
+    plan->timed = sync || !(exec_flags & DFFT_EXEC_NO_TIMING);
+    if (!plan->timed && (exec_flags & DFFT_EXEC_PRINT)) return fail(DFFT_EINVAL, "dfft_execute: PRINT needs stage timing");
     int rc = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
              : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
                                                : execute_backward(plan, sync);
@@ -946,6 +949,7 @@ int dfft_plan_sync(dfft_plan_t plan) {
 int dfft_stage_times(dfft_plan_t plan, double t[4]) {
     if (!plan || !t) return fail(DFFT_EINVAL, "dfft_stage_times: bad arguments");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    if (!plan->timed) return fail(DFFT_EINVAL, "dfft_stage_times: the last execute ran with DFFT_EXEC_NO_TIMING");
     if (plan->host_timed) {
         for (int i = 0; i < 4; ++i) t[i] = plan->host_t[i];
         return DFFT_OK;
@@ -960,7 +964,8 @@ int dfft_stage_times(dfft_plan_t plan, double t[4]) {
 
 int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
     if (!plan || !t) return fail(DFFT_EINVAL, "dfft_kernel_times: bad arguments");
-    if (plan->host_timed) return fail(DFFT_EINVAL, "dfft_kernel_times: needs an execute without DFFT_EXEC_SYNC_STAGES");
+    if (plan->host_timed || !plan->timed)
+        return fail(DFFT_EINVAL, "dfft_kernel_times: needs an execute without DFFT_EXEC_SYNC_STAGES / DFFT_EXEC_NO_TIMING");
     if (plan->flags & DFFT_PLAN_UNFUSED) return fail(DFFT_EINVAL, "dfft_kernel_times: fused plans only");
     if (plan->chunk_planes > 0 || plan->part_planes > 0)
         return fail(DFFT_EINVAL, "dfft_kernel_times: Z and Y launches are interleaved per cache chunk (set DFFT_CHUNK_MB=0)");

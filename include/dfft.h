@@ -59,6 +59,9 @@ extern "C" {
 #define DFFT_EXEC_ASYNC 0u          /* enqueue on the plan's stream and return */
 #define DFFT_EXEC_SYNC_STAGES 1u    /* hipDeviceSynchronize-style host timing per stage, like fft_mpi_3d_api.cpp:184-201 */
 #define DFFT_EXEC_PRINT 2u          /* print the reference's "t0: .. t1: .. t2: .. t3: .. total: .." line (forward only) */
+#define DFFT_EXEC_NO_TIMING 4u      /* do not record the stage-boundary events (dfft_stage_times is then unavailable): a
+                                       production loop of small transforms is launch-bound, and the 5-6 event records per
+                                       execute are as many queue packets as the kernels themselves */
 
 typedef struct dfft_plan_s* dfft_plan_t;
 typedef struct dfft_comm_s* dfft_comm_t;

@@ -217,6 +217,28 @@ def test_rccl_single_rank_communicator(gpu):
     comm.destroy()
 
 
+def test_execute_without_stage_events(gpu):
+    """DFFT_EXEC_NO_TIMING: same result, no stage-boundary events; asking for stage times afterwards is an error, and
+    the next timed execute brings them back."""
+    import torch
+    from distributedfft_amd import api
+    N = (32, 16, 24)
+    x = so.random_input(N, seed=31)
+    ref = so.fftn_reference(x, 1)[0]
+    a = torch.from_numpy(x.reshape(-1)).to(gpu)
+    b = torch.zeros_like(a)
+    torch.cuda.synchronize()
+    plan = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+    plan.execute(api.EXEC_NO_TIMING)
+    plan.sync()
+    assert np.abs(b.cpu().numpy().reshape(ref.shape) - ref).max() / np.abs(ref).max() < 1e-11
+    with pytest.raises(api.DfftError):
+        plan.stage_times()
+    plan.execute()
+    assert len(plan.stage_times()) == 4
+    plan.destroy()
+
+
 def test_unsupported_length_fails_loudly(gpu):
     import torch
     from distributedfft_amd import api
