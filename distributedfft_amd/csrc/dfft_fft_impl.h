@@ -406,7 +406,11 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE;
     constexpr int NREL = PLAIN ? 1 : E;
     constexpr int ON = N / LANES;  // staged store: memory elements (GV) per scalar column
-    unsigned irel[NREL], orel[NREL];
+    // staged store with ON a multiple of the group size (every power-of-two plan): the element a thread stores at step k is
+    // tid + const_k in scalar column const'_k, so its offset is tid + C1_k + C2_k * cstride -- no per-point register
+    // (and likewise when the group size is a multiple of ON: column tid / ON + const_k, element tid % ON)
+    constexpr bool OAFFINE = KG::OSTAGE && (ON % GT == 0 || GT % ON == 0);
+    unsigned irel[NREL], orel[OAFFINE ? 1 : NREL];
     unsigned ilast = 0, olast = 0;
     const unsigned istep = (unsigned)(T * imap.stride), ostep = (unsigned)(T * omap.stride);
     if constexpr (PLAIN) {
@@ -422,14 +426,28 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         // staged store: thread owns the linear memory elements tid + GT*k of the [CB*LANES scalar columns][ON] result
         // tile (omap.cstride is then the distance between SCALAR columns, omap.stride the one between memory elements)
         // (two-phase tiles: points [0, E/2) belong to the image of columns [0, CB/2), the rest to the second image)
-        constexpr int EPH = E / KG::PH;
-        const int lin_o = tid + GT * (k % EPH);
-        const int oc = KG::OSTAGE ? (k / EPH) * (CB / KG::PH) * LANES + lin_o / ON : c;
-        const int oidx = KG::OSTAGE ? lin_o % ON : idx;
-        const int ob = oidx / omap.blk;
-        orel[k] = (unsigned)(block_term(omap, ob) + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
-        if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
+        if constexpr (!OAFFINE) {
+            constexpr int EPH = E / KG::PH;
+            const int lin_o = tid + GT * (k % EPH);
+            const int oc = KG::OSTAGE ? (k / EPH) * (CB / KG::PH) * LANES + lin_o / ON : c;
+            const int oidx = KG::OSTAGE ? lin_o % ON : idx;
+            const int ob = oidx / omap.blk;
+            orel[k] = (unsigned)(block_term(omap, ob) + (oidx - ob * omap.blk) * omap.stride + oc * omap.cstride);
+            if (GENERAL && ob == omap.nblk - 1) olast |= 1u << k;
+        }
     }
+    // offset of staged-store step k (k is a compile-time constant after unrolling)
+    const long long obase = OAFFINE ? (ON % GT == 0 ? (long long)tid : (long long)(tid % ON) + (long long)(tid / ON) * omap.cstride) : 0;
+    auto ostage_off = [&](int k) -> long long {
+        if constexpr (OAFFINE) {
+            constexpr int EPH = E / KG::PH;
+            const int kl = k % EPH;
+            const int oc = (k / EPH) * (CB / KG::PH) * LANES + (GT * kl) / ON;  // exact in both cases
+            return obase + (ON % GT == 0 ? (GT * kl) % ON : 0) + (long long)oc * omap.cstride;
+        } else {
+            return (long long)orel[k];
+        }
+    };
 
     const unsigned tstep = gridDim.x * G;
     // loads the E points of the tile group starting at t into dst (zeros for tiles / columns past the end)
@@ -500,7 +518,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
                     for (int k = 0; k < E; ++k) {
                         const int lin = tid + GT * k;
                         const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
-                        gstore<Tune::NTS>(op + (long long)orel[PLAIN ? 0 : k], r);
+                        gstore<Tune::NTS>(op + ostage_off(k), r);
                     }
                 }
             } else {
@@ -522,7 +540,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
                         for (int k = 0; k < EPH; ++k) {
                             const int lin = tid + GT * k;
                             const GV r = *reinterpret_cast<const GV*>(img + (lin / ON) * ROW + (lin % ON) * LANES);
-                            gstore<Tune::NTS>(op + (long long)orel[ph * EPH + k], r);
+                            gstore<Tune::NTS>(op + ostage_off(ph * EPH + k), r);
                         }
                     }
                 }
