@@ -111,6 +111,14 @@ class Comm:
         L.check(L.load().dfft_comm_create_rccl(unique_id, total_devices, global_idx, C.byref(h)), "dfft_comm_create_rccl")
         return Comm(h, "rccl", total_devices)
 
+    @staticmethod
+    def ipc(total_devices: int, global_idx: int) -> "Comm":
+        """One process per device without RCCL: hipIpc-shared receive buffers, device-to-device pushes, barriers over the
+        dfft_boot_* rendezvous (DFFT_RANK/... or torchrun's RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT)."""
+        h = C.c_void_p()
+        L.check(L.load().dfft_comm_create_ipc(total_devices, global_idx, C.byref(h)), "dfft_comm_create_ipc")
+        return Comm(h, "ipc", total_devices)
+
     def destroy(self):
         if self.handle:
             L.load().dfft_comm_destroy(self.handle)

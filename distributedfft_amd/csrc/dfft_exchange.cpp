@@ -21,16 +21,20 @@
 #include "dfft_internal.h"
 
 struct dfft_comm_s {
-    int kind = 0;  // 0 local, 1 rccl
+    int kind = 0;  // 0 local (threads of one process), 1 rccl, 2 ipc (one process per device, host-synchronised peer copies)
     int P = 1;
     // local
     std::mutex              m;
     std::condition_variable cv;
     int                     arrived = 0;
     unsigned long           generation = 0;
-    std::vector<void*>      recvbufs;  // [slot * P + device]: slot 0 = forward plans, 1 = backward plans (the reference
-                                       // shares one node_data[] between both and aliases them, fftSpeed3d_c2c.cpp:74,80)
-    std::vector<int>        devices;
+    // Receive buffers by registration: every plan registers its receive buffer(s) in creation order, and plans are created
+    // in the same order on every device thread / process, so registration r of device q is the buffer device q's r-th
+    // exchange descriptor receives into (the reference shares ONE node_data[] between its forward and backward plan and
+    // aliases them, fftSpeed3d_c2c.cpp:74,80; here any number of plans can be alive on one communicator).
+    std::vector<std::vector<void*>> regs;      // [registration][device]
+    std::vector<int>                next_reg;  // per device (local) / [rank] (ipc)
+    std::vector<int>                devices;
     // rccl
     ncclComm_t nccl = nullptr;
     int        rank = 0;
@@ -43,6 +47,7 @@ int comm_kind(dfft_comm_t c) { return c->kind; }
 int comm_size(dfft_comm_t c) { return c->P; }
 
 int comm_thread_barrier(dfft_comm_t c) {
+    if (c->kind == 2) return dfft_boot_barrier();  // processes instead of threads: the TCP rendezvous is the barrier
     if (c->kind != 0 || c->P <= 1) return DFFT_OK;
     std::unique_lock<std::mutex> lk(c->m);
     const unsigned long gen = c->generation;
@@ -56,23 +61,59 @@ int comm_thread_barrier(dfft_comm_t c) {
     return DFFT_OK;
 }
 
-int comm_register(dfft_comm_t c, int me, int slot, void* recvbuf, int device) {
-    if (me < 0 || me >= c->P || slot < 0 || slot > 1) return fail(DFFT_EINVAL, "comm_register: index out of range");
+int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out) {
+    if (me < 0 || me >= c->P || !reg_out) return fail(DFFT_EINVAL, "comm_register: index out of range");
+    *reg_out = -1;
     if (c->kind == 0) {
         std::lock_guard<std::mutex> lk(c->m);
-        c->recvbufs[(size_t)slot * c->P + me] = recvbuf;
+        const int reg = c->next_reg[me]++;
+        if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
+        c->regs[reg][me] = recvbuf;
         c->devices[me] = device;
+        *reg_out = reg;
+    } else if (c->kind == 2) {
+        // collective over all processes: every rank publishes the IPC handle of its receive buffer and maps the others'
+        if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the process rank");
+        const int reg = c->next_reg[me]++;
+        if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
+        hipIpcMemHandle_t mine;
+        DFFT_HIP_TRY(hipIpcGetMemHandle(&mine, recvbuf));
+        for (int q = 0; q < c->P; ++q) {
+            hipIpcMemHandle_t h = mine;
+            int               rc = dfft_boot_bcast(&h, sizeof(h), q);
+            if (rc) return rc;
+            if (q == me) {
+                c->regs[reg][q] = recvbuf;
+            } else {
+                void* ptr = nullptr;
+                DFFT_HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+                c->regs[reg][q] = ptr;
+            }
+            c->devices[q] = -1;  // reached through an IPC mapping, not through a device ordinal of this process
+        }
+        *reg_out = reg;
     } else {
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the RCCL rank");
+        *reg_out = 0;  // receivers post their own ncclRecv: nothing to look up
     }
     return DFFT_OK;
 }
 
-int comm_unregister(dfft_comm_t c, int me, int slot, void* recvbuf) {
-    if (c->kind == 0 && me >= 0 && me < c->P && slot >= 0 && slot <= 1) {
+int comm_unregister(dfft_comm_t c, int me, int reg) {
+    if (reg < 0 || me < 0 || me >= c->P) return DFFT_OK;
+    if (c->kind == 0) {
         std::lock_guard<std::mutex> lk(c->m);
-        void*& r = c->recvbufs[(size_t)slot * c->P + me];
-        if (r == recvbuf) r = nullptr;
+        if (reg < (int)c->regs.size()) c->regs[reg][me] = nullptr;
+    } else if (c->kind == 2 && reg < (int)c->regs.size()) {
+        // collective (plans are destroyed in the same order everywhere): unmap the peers' buffers, and only then may their
+        // owners free them
+        for (int q = 0; q < c->P; ++q) {
+            void*& r = c->regs[reg][q];
+            if (r && q != c->rank) (void)hipIpcCloseMemHandle(r);
+            r = nullptr;
+        }
+        (void)hipGetLastError();
+        return dfft_boot_barrier();
     }
     return DFFT_OK;
 }
@@ -204,7 +245,7 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
         int   dstdev;
         {
             std::lock_guard<std::mutex> lk(c->m);
-            dstbase = c->recvbufs[(size_t)x.slot * c->P + m.peer];
+            dstbase = (x.slot >= 0 && x.slot < (int)c->regs.size()) ? c->regs[x.slot][m.peer] : nullptr;
             dstdev = c->devices[m.peer];
         }
         if (!dstbase) return fail(DFFT_ECOMM, "local exchange: peer plan is not registered");
@@ -213,7 +254,7 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
         char*        dst = (char*)dstbase + (size_t)m.doff * eb;
         const char*  src = (const char*)x.sendbuf + (size_t)m.so * eb;
         const size_t bytes = (size_t)m.sc * eb;
-        if (dstdev == mydev) DFFT_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+        if (dstdev == mydev || dstdev < 0) DFFT_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
         else DFFT_HIP_TRY(hipMemcpyPeerAsync(dst, dstdev, src, mydev, bytes, stream));
     }
     DFFT_HIP_TRY(hipStreamSynchronize(stream));
@@ -278,7 +319,7 @@ void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, st
 
 int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
     const Round r = whole_round(x);
-    if (c->kind == 0) return exchange_local(c, x, r, stream);
+    if (c->kind != 1) return exchange_local(c, x, r, stream);
     return exchange_rccl(c, x, r, stream);
 }
 
@@ -286,7 +327,7 @@ int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp
     if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0 || ycut >= x.ycuts)
         return fail(DFFT_EINVAL, "comm_exchange_part: descriptor has no plane geometry");
     const Round r = part_round(x, k, cp, ycut);
-    if (c->kind == 0) return exchange_local(c, x, r, stream);
+    if (c->kind != 1) return exchange_local(c, x, r, stream);
     return exchange_rccl(c, x, r, stream);
 }
 
@@ -301,8 +342,29 @@ int dfft_comm_create_local(int total_devices, dfft_comm_t* comm) {
     dfft_comm_s* c = new dfft_comm_s;
     c->kind = 0;
     c->P = total_devices;
-    c->recvbufs.assign(2 * (size_t)total_devices, nullptr);
+    c->next_reg.assign(total_devices, 0);
     c->devices.assign(total_devices, 0);
+    *comm = c;
+    return DFFT_OK;
+}
+
+int dfft_comm_create_ipc(int total_devices, int global_idx, dfft_comm_t* comm) {
+    if (total_devices < 1 || !comm || global_idx < 0 || global_idx >= total_devices)
+        return fail(DFFT_EINVAL, "dfft_comm_create_ipc: bad arguments");
+    int rc = dfft_boot_init();
+    if (rc) return rc;
+    if (dfft_boot_size() != total_devices || dfft_boot_rank() != global_idx)
+        return fail(DFFT_ECOMM, "dfft_comm_create_ipc: one process per device -- the rendezvous' rank/size must equal global_idx/total_devices");
+    dfft_comm_s* c = new dfft_comm_s;
+    c->kind = 2;
+    c->P = total_devices;
+    c->rank = global_idx;
+    c->next_reg.assign(total_devices, 0);
+    c->devices.assign(total_devices, -1);
+    if (hipGetDevice(&c->device) != hipSuccess) {
+        delete c;
+        return fail(DFFT_ENOGPU, "dfft_comm_create_ipc: no HIP device");
+    }
     *comm = c;
     return DFFT_OK;
 }

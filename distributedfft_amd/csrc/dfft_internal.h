@@ -41,7 +41,7 @@ struct ExchangeDesc {
     int                    dtype;
     int                    P, me;
     int                    direction = DFFT_FORWARD;  // X -> Y slabs (forward) or Y -> X slabs (backward)
-    int                    slot = 0;  // 0 forward, 1 backward: which registered receive buffer of the peers to push into
+    int                    slot = -1;  // registration id (comm_register): which receive buffer of the peers to push into
     void*                  sendbuf;  // bufferDev2
     void*                  recvbuf;  // bufferDev1 (this device's; peers' are looked up through the communicator)
     std::vector<long long> scount, soffset, rcount, roffset;  // elements, indexed by peer
@@ -67,9 +67,10 @@ inline void part_range(long long xs_g, long long cp, int k, long long* x0, long 
     *nx = b - a;
 }
 
-// slot: 0 for forward plans, 1 for backward plans (each direction has its own receive buffer per device)
-int comm_register(dfft_comm_t comm, int me, int slot, void* recvbuf, int device);
-int comm_unregister(dfft_comm_t comm, int me, int slot, void* recvbuf);
+// Registers device `me`'s receive buffer and returns its registration id (ExchangeDesc::slot).  Plans must be created in
+// the same order on every device thread / process; the IPC communicator makes this call collective.
+int comm_register(dfft_comm_t comm, int me, void* recvbuf, int device, int* reg);
+int comm_unregister(dfft_comm_t comm, int me, int reg);
 int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl
 int comm_size(dfft_comm_t comm);
 // Local: host-synchronising collective (thread barrier + peer copies); RCCL: enqueued on `stream`.

@@ -859,7 +859,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     fill_exchange(p, p->xd, natural ? DFFT_FORWARD : direction);
     p->xd.sendbuf = p->buf2;
     p->xd.recvbuf = p->buf1;
-    p->xd.slot = (natural || direction == DFFT_FORWARD) ? 0 : 1;
+    p->xd.slot = p->xd2.slot = -1;  // registration ids, set below
     if (natural && p->exch) {
         // natural-order plans re-slab twice (X->Y for the X pass, Y->X to return to the caller's layout); the second
         // exchange receives the packed [src][xs][yl_src][N2] blocks into a buffer of its own and uses the other slot
@@ -871,8 +871,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         fill_exchange(p, p->xd2, DFFT_BACKWARD);
         p->xd2.sendbuf = p->buf2;
         p->xd2.recvbuf = p->rbuf;
-        p->xd2.slot = 1;
-        int rc = comm_register(comm, global_idx, 1, p->rbuf, p->device);
+        int rc = comm_register(comm, global_idx, p->rbuf, p->device, &p->xd2.slot);
         if (rc) {
             dfft_plan_destroy(p);
             return rc;
@@ -891,7 +890,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         p->xd.ycuts = p->ycuts;
     }
     if (comm) {
-        int rc = comm_register(comm, global_idx, p->xd.slot, p->xd.recvbuf, p->device);  // nodeDataDev[loc] = bufferDev1, :80
+        int rc = comm_register(comm, global_idx, p->xd.recvbuf, p->device, &p->xd.slot);  // nodeDataDev[loc] = bufferDev1, :80
         if (rc) {
             dfft_plan_destroy(p);
             return rc;
@@ -990,8 +989,10 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (!plan) return DFFT_OK;
     if (plan->stream) hipStreamSynchronize(plan->stream);
     if (plan->stream2) hipStreamSynchronize(plan->stream2);
-    if (plan->comm) comm_unregister(plan->comm, plan->me, plan->xd.slot, plan->xd.recvbuf);
-    if (plan->comm && (plan->flags & DFFT_PLAN_NATURAL)) comm_unregister(plan->comm, plan->me, 1, plan->rbuf);
+    if (plan->comm) {  // same order as the registrations (the IPC communicator makes these collective)
+        comm_unregister(plan->comm, plan->me, plan->xd2.slot);
+        comm_unregister(plan->comm, plan->me, plan->xd.slot);
+    }
     for (auto& e : plan->ev)
         if (e) hipEventDestroy(e);
     for (auto& e : plan->part_ev)

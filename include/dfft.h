@@ -112,6 +112,14 @@ int dfft_comm_create_local(int total_devices, dfft_comm_t* comm);
 /* 128-byte RCCL unique id; rank 0 creates it and the host distributes it (torch.distributed, MPI, dfft_boot_*). */
 int dfft_rccl_unique_id(char id[128]);
 int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx, dfft_comm_t* comm);
+/* IPC   : one process per device WITHOUT RCCL: the receive buffers are shared through hipIpc handles (exchanged over the
+ *         dfft_boot_* rendezvous, which must describe exactly these processes), peers push their chunks with device-to-device
+ *         copies (SDMA engines, no CUs), and the processes synchronise through the rendezvous' barrier -- the cross-process
+ *         twin of the LOCAL communicator, i.e. the reference's MPI path with hipMemcpy instead of UCX (fft_mpi_3d_api.cpp:
+ *         635-672).  Host-synchronising, so slower than RCCL for small messages; it also works with several processes sharing
+ *         one GPU, which is how the multi-process path is tested on a single-GPU machine.  Plan creation and destruction are
+ *         collective over the processes. */
+int dfft_comm_create_ipc(int total_devices, int global_idx, dfft_comm_t* comm);
 int dfft_comm_destroy(dfft_comm_t comm);
 
 /* ---- memory ------------------------------------------------------------------------------------------------------------
