@@ -15,6 +15,20 @@ fi
 
 NGPU=$("$BIN" --device-count 2>/dev/null | tail -1)
 NGPU=${NGPU:-0}
+if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ] && [ "$NGPU" -gt 0 ] && [ "${DFFT_EXCHANGE:-}" = "ipc" ]; then
+    # fewer GPUs than ranks, multi-process anyway: the hipIpc communicator lets several ranks share a GPU (round-robin)
+    echo "speedTest.sh: $NGPU GPU(s) for $NP ranks -> $NP processes sharing them (DFFT_EXCHANGE=ipc)" >&2
+    PORT=${DFFT_MASTER_PORT:-29533}
+    pids=()
+    for ((r = 0; r < NP; r++)); do
+        DFFT_RANK=$r DFFT_WORLD_SIZE=$NP DFFT_MASTER_ADDR=127.0.0.1 DFFT_MASTER_PORT=$PORT DFFT_LOCAL_DEVICE=$((r % NGPU)) \
+            DFFT_VIRTUAL_DEVICES=1 "$BIN" $2 $3 $4 1 &
+        pids+=($!)
+    done
+    rc=0
+    for p in "${pids[@]}"; do wait "$p" || rc=$?; done
+    exit $rc
+fi
 if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ]; then
     # fewer GPUs than ranks: drive <MPI-RANK> virtual devices from one process (GPU_COUNT = $NP), sharing the GPUs
     # round-robin like the reference driver's hipSetDevice(globalIdx % devCount) (fftSpeed3d_c2c.cpp:53)

@@ -109,6 +109,27 @@ def test_one_process_per_slab_on_one_gpu(gpu, N, world):
         assert f"MP-OK {r}" in o
 
 
+@pytest.mark.parametrize("ranks,overlap", [(2, "0"), (4, "1")])
+def test_speedtest_sh_multi_process_driver(gpu, tmp_path, ranks, overlap):
+    """sh speedTest.sh <ranks> X Y Z with one process per rank (the reference's mpirun -np <ranks> ./distFFTOpt X Y Z 1,
+    speedTest.sh:6): TCP rendezvous instead of MPI, hipIpc exchange so the ranks can share the one GPU; the driver's own
+    report block and round-trip error metric, also with the overlapped forward pipeline (DFFT_OVERLAP=1)."""
+    import re
+    env = dict(os.environ, DFFT_EXCHANGE="ipc", DFFT_MASTER_PORT=str(_free_port()), DFFT_OVERLAP=overlap,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(["bash", str(ROOT / "speedTest.sh"), str(ranks), "64", "32", "48"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = r.stdout
+    assert re.search(r"Size:\s*64x32x48", out) and re.search(rf"MPI ranks:\s*{ranks}\b", out)
+    assert float(re.search(r"Max error:\s*([0-9.eE+-]+)", out).group(1)) < 1e-11
+    assert float(re.search(r"Performance:\s*([0-9.eE+-]+)", out).group(1)) > 0
+    nlines = out.count("t0: ")              # one stage line per forward execute per rank (the ranks share the pipe)
+    assert nlines >= 2 * ranks and nlines % ranks == 0
+
+
 @pytest.mark.parametrize("world,size", [(2, "64"), (4, "128")])
 def test_bench_multirank_flow_with_real_data(gpu, world, size):
     """bench.py --gpus W exactly as the driver launches it (one rank per process, torchrun-style environment), with the IPC
