@@ -63,10 +63,15 @@ template <class Real> static int run(long long n0, long long n1, long long n2, i
     }
     dfft_comm_t comm = nullptr;
     if (nprocs > 1) {
-        char id[128];
-        if (me == 0) CHECK_DFFT(dfft_rccl_unique_id(id));
-        CHECK_DFFT(dfft_boot_bcast(id, sizeof(id), 0));
-        CHECK_DFFT(dfft_comm_create_rccl(id, nprocs, me, &comm));
+        const char* ex = getenv("DFFT_EXCHANGE");
+        if (ex && std::string(ex) == "ipc") {  // hipIpc peer copies: no RCCL, ranks may share a GPU
+            CHECK_DFFT(dfft_comm_create_ipc(nprocs, me, &comm));
+        } else {
+            char id[128];
+            if (me == 0) CHECK_DFFT(dfft_rccl_unique_id(id));
+            CHECK_DFFT(dfft_boot_bcast(id, sizeof(id), 0));
+            CHECK_DFFT(dfft_comm_create_rccl(id, nprocs, me, &comm));
+        }
     }
     const long long count = dfft_local_count(N, nprocs, me);
     const long long cap = dfft_max_count(n0, n1, n2, nprocs, me == nprocs - 1);

@@ -130,6 +130,31 @@ def test_speedtest_sh_multi_process_driver(gpu, tmp_path, ranks, overlap):
     assert nlines >= 2 * ranks and nlines % ranks == 0
 
 
+@pytest.mark.parametrize("world,precision,tol", [(2, "double", 1e-11), (3, "float", 5e-4)])
+def test_heffte_protocol_front_end_multi_process(gpu, world, precision, tol):
+    """speed3d_c2c (heFFTe's benchmark protocol on the C-ABI) with one process per slab: natural-order plans, i.e. two
+    all-to-alls per transform, forward scaled by 1/N in the X pass, backward, heFFTe's tolerance."""
+    import re
+    from distributedfft_amd import _lib
+    exe = _lib.LIB_PATH.parent / "speed3d_c2c"
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, DFFT_RANK=str(r), DFFT_WORLD_SIZE=str(world), DFFT_MASTER_ADDR="127.0.0.1",
+                   DFFT_MASTER_PORT=str(port), DFFT_LOCAL_DEVICE="0", DFFT_EXCHANGE="ipc", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([str(exe), "stock", precision, "48", "36", "24", "-slabs"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, (o + e)[-2000:]
+    out = outs[0][0]
+    assert "heFFTe performance test" in out and "Size:      48x36x24" in out
+    assert float(re.search(r"Max error:\s*([0-9.eE+-]+)", out).group(1)) < tol
+    assert float(re.search(r"Time per run:\s*([0-9.eE+-]+)", out).group(1)) > 0
+
+
 @pytest.mark.parametrize("world,size", [(2, "64"), (4, "128")])
 def test_bench_multirank_flow_with_real_data(gpu, world, size):
     """bench.py --gpus W exactly as the driver launches it (one rank per process, torchrun-style environment), with the IPC
