@@ -129,7 +129,8 @@ def main():
         if not args.dry_run:
             # DFFT_EXCHANGE=ipc: hipIpc peer copies + rendezvous barriers instead of RCCL (also works with several ranks on
             # one GPU -- how this multi-rank path is exercised on a single-GPU box); default: RCCL over xGMI
-            comm = api.Comm.ipc(P, rank) if exchange_backend == "ipc" else api.Comm.rccl(uid_bytes, P, rank)
+            comm = (api.Comm.ipc(P, rank, exchange_backend == "ipc-async") if exchange_backend in ("ipc", "ipc-async")
+                    else api.Comm.rccl(uid_bytes, P, rank))
     if args.dry_run:
         tot, inr, counts = api.fft_mpi_init(args.size, 1, mpi_size=P, mpi_rank=rank)
         lay = api.exchange_layout(*args.size, P, rank, api.FORWARD)
@@ -411,7 +412,8 @@ def main():
                        "parallelism": f"slab{P}",
                        "exchange": "none (P=1)" if P == 1 else
                                    ("hipIpc peer copies + rendezvous barriers (DFFT_EXCHANGE=ipc)" if exchange_backend == "ipc"
-                                    else "RCCL grouped send/recv over xGMI") +
+                                    else "hipIpc peer copies + stream-ordered flag words (DFFT_EXCHANGE=ipc-async)"
+                                    if exchange_backend == "ipc-async" else "RCCL grouped send/recv over xGMI") +
                                    (", X-plane parts overlapped with t0 on a second stream (stages_ms.t2 = exposed part)" if overlap else "")},
             "max_error": rt_err / 1e7, "roundtrip_abs_error": rt_err,
             "direct_dft_spot_check_rel_error": spot_err,  # 5 output elements against the defining sum over all ranks' input

@@ -112,12 +112,13 @@ class Comm:
         return Comm(h, "rccl", total_devices)
 
     @staticmethod
-    def ipc(total_devices: int, global_idx: int) -> "Comm":
+    def ipc(total_devices: int, global_idx: int, async_exchange: bool = False) -> "Comm":
         """One process per device without RCCL: hipIpc-shared receive buffers, device-to-device pushes, barriers over the
         dfft_boot_* rendezvous (DFFT_RANK/... or torchrun's RANK/WORLD_SIZE/MASTER_ADDR/MASTER_PORT)."""
         h = C.c_void_p()
-        L.check(L.load().dfft_comm_create_ipc(total_devices, global_idx, C.byref(h)), "dfft_comm_create_ipc")
-        return Comm(h, "ipc", total_devices)
+        L.check(L.load().dfft_comm_create_ipc(total_devices, global_idx, 1 if async_exchange else 0, C.byref(h)),
+                "dfft_comm_create_ipc")
+        return Comm(h, "ipc-async" if async_exchange else "ipc", total_devices)
 
     def destroy(self):
         if self.handle:

@@ -35,15 +35,51 @@ struct dfft_comm_s {
     std::vector<std::vector<void*>> regs;      // [registration][device]
     std::vector<int>                next_reg;  // per device (local) / [rank] (ipc)
     std::vector<int>                devices;
+    // ipc with stream-ordered synchronisation (kind 3): per registration, flag words shared like the receive buffers
+    // (2*P words per device: ready[src], arrive[src]), a round counter, and a pinned host word a timed-out kernel sets
+    std::vector<std::vector<unsigned long long*>> flag_regs;  // [registration][device]
+    std::vector<unsigned long long>               seq;        // rounds issued per registration
+    unsigned long long*                           err = nullptr;
     // rccl
     ncclComm_t nccl = nullptr;
     int        rank = 0;
     int        device = 0;
 };
 
+namespace {
+// Cross-process, stream-ordered synchronisation of the asynchronous IPC exchange: lane i publishes `seq` to sig[i] (a flag
+// word in a peer's memory), then lane i waits until wait[i] (a flag word in this device's memory) has reached `seq`.
+// Bounded: after ~20 s the kernel gives up and reports through the pinned `err` word instead of hanging the device.
+struct IpcSyncLists {
+    unsigned long long*       sig[64];
+    const unsigned long long* wait[64];
+    int                       nsig, nwait;
+};
+__global__ void ipc_sync_kernel(IpcSyncLists L, unsigned long long seq, unsigned long long* err) {
+    const int i = threadIdx.x;
+    if (i < L.nsig) __hip_atomic_store(L.sig[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (i < L.nwait) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        while (__hip_atomic_load(L.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(16);
+            if (wall_clock64() - t0 > 2000000000ull) {
+                *err = seq;
+                break;
+            }
+        }
+    }
+}
+}  // namespace
+
 namespace dfft {
 
 int comm_kind(dfft_comm_t c) { return c->kind; }
+bool comm_is_async(dfft_comm_t c) { return c->kind == 1 || c->kind == 3; }
+int comm_check(dfft_comm_t c) {
+    if (c && c->kind == 3 && c->err && *(volatile unsigned long long*)c->err != 0)
+        return fail(DFFT_ECOMM, "ipc exchange: a peer did not answer within 20 s (round " + std::to_string(*c->err) + ")");
+    return DFFT_OK;
+}
 int comm_size(dfft_comm_t c) { return c->P; }
 
 int comm_thread_barrier(dfft_comm_t c) {
@@ -71,25 +107,46 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
         c->regs[reg][me] = recvbuf;
         c->devices[me] = device;
         *reg_out = reg;
-    } else if (c->kind == 2) {
+    } else if (c->kind == 2 || c->kind == 3) {
         // collective over all processes: every rank publishes the IPC handle of its receive buffer and maps the others'
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the process rank");
         const int reg = c->next_reg[me]++;
         if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
-        hipIpcMemHandle_t mine;
-        DFFT_HIP_TRY(hipIpcGetMemHandle(&mine, recvbuf));
-        for (int q = 0; q < c->P; ++q) {
-            hipIpcMemHandle_t h = mine;
-            int               rc = dfft_boot_bcast(&h, sizeof(h), q);
-            if (rc) return rc;
-            if (q == me) {
-                c->regs[reg][q] = recvbuf;
-            } else {
-                void* ptr = nullptr;
-                DFFT_HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
-                c->regs[reg][q] = ptr;
+        auto share = [&](void* local, std::vector<void*>& out) -> int {
+            hipIpcMemHandle_t mine;
+            DFFT_HIP_TRY(hipIpcGetMemHandle(&mine, local));
+            for (int q = 0; q < c->P; ++q) {
+                hipIpcMemHandle_t h = mine;
+                int               rc = dfft_boot_bcast(&h, sizeof(h), q);
+                if (rc) return rc;
+                if (q == me) {
+                    out[q] = local;
+                } else {
+                    void* ptr = nullptr;
+                    DFFT_HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+                    out[q] = ptr;
+                }
             }
-            c->devices[q] = -1;  // reached through an IPC mapping, not through a device ordinal of this process
+            return DFFT_OK;
+        };
+        int rc = share(recvbuf, c->regs[reg]);
+        if (rc) return rc;
+        for (int q = 0; q < c->P; ++q) c->devices[q] = -1;  // reached through IPC mappings, not through device ordinals
+        if (c->kind == 3) {
+            // flag words of this registration: fine-grained so that a peer's store is visible to a kernel spinning here
+            if ((int)c->flag_regs.size() <= reg) {
+                c->flag_regs.resize(reg + 1, std::vector<unsigned long long*>(c->P, nullptr));
+                c->seq.resize(reg + 1, 0);
+            }
+            void* f = nullptr;
+            DFFT_HIP_TRY(hipExtMallocWithFlags(&f, 2 * (size_t)c->P * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+            DFFT_HIP_TRY(hipMemset(f, 0, 2 * (size_t)c->P * sizeof(unsigned long long)));
+            DFFT_HIP_TRY(hipDeviceSynchronize());
+            std::vector<void*> fl(c->P, nullptr);
+            rc = share(f, fl);
+            if (rc) return rc;
+            for (int q = 0; q < c->P; ++q) c->flag_regs[reg][q] = (unsigned long long*)fl[q];
+            c->seq[reg] = 0;
         }
         *reg_out = reg;
     } else {
@@ -104,7 +161,7 @@ int comm_unregister(dfft_comm_t c, int me, int reg) {
     if (c->kind == 0) {
         std::lock_guard<std::mutex> lk(c->m);
         if (reg < (int)c->regs.size()) c->regs[reg][me] = nullptr;
-    } else if (c->kind == 2 && reg < (int)c->regs.size()) {
+    } else if ((c->kind == 2 || c->kind == 3) && reg < (int)c->regs.size()) {
         // collective (plans are destroyed in the same order everywhere): unmap the peers' buffers, and only then may their
         // owners free them
         for (int q = 0; q < c->P; ++q) {
@@ -112,8 +169,19 @@ int comm_unregister(dfft_comm_t c, int me, int reg) {
             if (r && q != c->rank) (void)hipIpcCloseMemHandle(r);
             r = nullptr;
         }
+        unsigned long long* own_flags = nullptr;
+        if (c->kind == 3 && reg < (int)c->flag_regs.size()) {
+            for (int q = 0; q < c->P; ++q) {
+                unsigned long long*& f = c->flag_regs[reg][q];
+                if (f && q != c->rank) (void)hipIpcCloseMemHandle(f);
+                if (q == c->rank) own_flags = f;
+                f = nullptr;
+            }
+        }
         (void)hipGetLastError();
-        return dfft_boot_barrier();
+        int rc = dfft_boot_barrier();
+        if (own_flags) (void)hipFree(own_flags);
+        return rc;
     }
     return DFFT_OK;
 }
@@ -262,6 +330,49 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
     return DFFT_OK;
 }
 
+// Asynchronous IPC exchange (kind 3): everything is enqueued on `stream`, nothing blocks the host.
+//   sync 1: tell every source "my receive regions of this round are free", wait for the same word from every destination
+//   push  : device-to-device copies into the peers' IPC-mapped receive buffers (SDMA engines, no CUs)
+//   sync 2: tell every destination "your data has landed", wait for the same word from every source
+// Both ends issue the rounds of a registration in the same order, so one monotonically increasing word per pair suffices.
+int exchange_ipc_async(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
+    const size_t eb = elem_bytes(x.dtype);
+    if (x.slot < 0 || x.slot >= (int)c->flag_regs.size()) return fail(DFFT_ECOMM, "ipc exchange: plan is not registered");
+    const unsigned long long seq = ++c->seq[x.slot];
+    const int                P = c->P, me = c->rank;
+    std::vector<char>        is_src(P, 0), is_dst(P, 0);
+    for (const Msg& m : r) {
+        if (m.peer == me) continue;
+        if (m.rc > 0) is_src[m.peer] = 1;
+        if (m.sc > 0) is_dst[m.peer] = 1;
+    }
+    unsigned long long* mine = c->flag_regs[x.slot][me];
+    IpcSyncLists        ready, arrive;
+    ready.nsig = ready.nwait = arrive.nsig = arrive.nwait = 0;
+    for (int q = 0; q < P; ++q) {
+        if (is_src[q]) {  // q will push into me
+            ready.sig[ready.nsig++] = c->flag_regs[x.slot][q] + me;         // q's ready[me]
+            arrive.wait[arrive.nwait++] = mine + P + q;                      // my arrive[q]
+        }
+        if (is_dst[q]) {  // I will push into q
+            ready.wait[ready.nwait++] = mine + q;                            // my ready[q]
+            arrive.sig[arrive.nsig++] = c->flag_regs[x.slot][q] + P + me;   // q's arrive[me]
+        }
+    }
+    (void)hipGetLastError();
+    if (ready.nsig || ready.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, ready, seq, c->err);
+    for (const Msg& m : r) {
+        if (m.sc == 0) continue;
+        void* dstbase = c->regs[x.slot][m.peer];
+        if (!dstbase) return fail(DFFT_ECOMM, "ipc exchange: peer buffer is not mapped");
+        DFFT_HIP_TRY(hipMemcpyAsync((char*)dstbase + (size_t)m.doff * eb, (const char*)x.sendbuf + (size_t)m.so * eb,
+                                    (size_t)m.sc * eb, hipMemcpyDeviceToDevice, stream));
+    }
+    if (arrive.nsig || arrive.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, arrive, seq, c->err);
+    DFFT_HIP_TRY(hipGetLastError());
+    return DFFT_OK;
+}
+
 int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
     const size_t         eb = elem_bytes(x.dtype);
     const ncclDataType_t ty = x.dtype == DFFT_F64 ? ncclDouble : ncclFloat;
@@ -319,6 +430,7 @@ void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, st
 
 int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
     const Round r = whole_round(x);
+    if (c->kind == 3) return exchange_ipc_async(c, x, r, stream);
     if (c->kind != 1) return exchange_local(c, x, r, stream);
     return exchange_rccl(c, x, r, stream);
 }
@@ -327,6 +439,7 @@ int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp
     if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0 || ycut >= x.ycuts)
         return fail(DFFT_EINVAL, "comm_exchange_part: descriptor has no plane geometry");
     const Round r = part_round(x, k, cp, ycut);
+    if (c->kind == 3) return exchange_ipc_async(c, x, r, stream);
     if (c->kind != 1) return exchange_local(c, x, r, stream);
     return exchange_rccl(c, x, r, stream);
 }
@@ -348,15 +461,15 @@ int dfft_comm_create_local(int total_devices, dfft_comm_t* comm) {
     return DFFT_OK;
 }
 
-int dfft_comm_create_ipc(int total_devices, int global_idx, dfft_comm_t* comm) {
-    if (total_devices < 1 || !comm || global_idx < 0 || global_idx >= total_devices)
-        return fail(DFFT_EINVAL, "dfft_comm_create_ipc: bad arguments");
+int dfft_comm_create_ipc(int total_devices, int global_idx, int async_exchange, dfft_comm_t* comm) {
+    if (total_devices < 1 || !comm || global_idx < 0 || global_idx >= total_devices || total_devices > 64)
+        return fail(DFFT_EINVAL, "dfft_comm_create_ipc: bad arguments (at most 64 devices)");
     int rc = dfft_boot_init();
     if (rc) return rc;
     if (dfft_boot_size() != total_devices || dfft_boot_rank() != global_idx)
         return fail(DFFT_ECOMM, "dfft_comm_create_ipc: one process per device -- the rendezvous' rank/size must equal global_idx/total_devices");
     dfft_comm_s* c = new dfft_comm_s;
-    c->kind = 2;
+    c->kind = async_exchange ? 3 : 2;
     c->P = total_devices;
     c->rank = global_idx;
     c->next_reg.assign(total_devices, 0);
@@ -364,6 +477,15 @@ int dfft_comm_create_ipc(int total_devices, int global_idx, dfft_comm_t* comm) {
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return fail(DFFT_ENOGPU, "dfft_comm_create_ipc: no HIP device");
+    }
+    if (c->kind == 3) {
+        void* e = nullptr;
+        if (hipHostMalloc(&e, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) {
+            delete c;
+            return fail(DFFT_EHIP, "dfft_comm_create_ipc: hipHostMalloc");
+        }
+        c->err = (unsigned long long*)e;
+        *c->err = 0;
     }
     *comm = c;
     return DFFT_OK;
@@ -403,6 +525,7 @@ int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx,
 int dfft_comm_destroy(dfft_comm_t comm) {
     if (!comm) return DFFT_OK;
     if (comm->kind == 1 && comm->nccl) ncclCommDestroy(comm->nccl);
+    if (comm->err) (void)hipHostFree(comm->err);
     delete comm;
     return DFFT_OK;
 }

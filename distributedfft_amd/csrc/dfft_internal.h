@@ -71,7 +71,9 @@ inline void part_range(long long xs_g, long long cp, int k, long long* x0, long 
 // the same order on every device thread / process; the IPC communicator makes this call collective.
 int comm_register(dfft_comm_t comm, int me, void* recvbuf, int device, int* reg);
 int comm_unregister(dfft_comm_t comm, int me, int reg);
-int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl
+int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl, 2 ipc (host-synchronised), 3 ipc (stream-ordered)
+bool comm_is_async(dfft_comm_t comm);  // exchanges are enqueued on the stream (rccl, ipc-async) instead of blocking the host
+int comm_check(dfft_comm_t comm);      // error reported by an asynchronous exchange since the last check
 int comm_size(dfft_comm_t comm);
 // Local: host-synchronising collective (thread barrier + peer copies); RCCL: enqueued on `stream`.
 int comm_exchange(dfft_comm_t comm, const ExchangeDesc& x, hipStream_t stream);

@@ -355,7 +355,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         // ---- t0 pipelined against t2: the exchange of plane part k (stream2) runs while the Z+Y passes of part k+1
         // (stream) compute.  Any X-plane sub-range of the packed send layout is contiguous on both sides, so the parts
         // need no extra packing (dfft_exchange.cpp).  All ranks cut their slabs with the same part size.
-        const bool rccl = comm_kind(p->comm) == 1;
+        const bool rccl = comm_is_async(p->comm);
         const int  K = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
         const int  YK = p->ycuts;
         for (int k = 0; k < K; ++k) {
@@ -491,7 +491,7 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
         // ---- mirror image of the overlapped forward pipeline: the inverse X pass runs Y sub-block by sub-block into the
         // send buffer [k][x all][y in k][N2] and sub-block k is exchanged (stream2) while sub-block k+1 is transformed;
         // the last sub-block is exchanged X-plane part by part, and the Y+Z passes of part i start when part i has landed.
-        const bool      rccl = comm_kind(p->comm) == 1;
+        const bool      rccl = comm_is_async(p->comm);
         const int       I = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
         const int       YK = p->ycuts;
         const long long ysub = p->ys / YK;
@@ -942,6 +942,7 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    if (plan->comm) return comm_check(plan->comm);
     return DFFT_OK;
 }
 

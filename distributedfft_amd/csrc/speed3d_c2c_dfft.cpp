@@ -64,8 +64,8 @@ template <class Real> static int run(long long n0, long long n1, long long n2, i
     dfft_comm_t comm = nullptr;
     if (nprocs > 1) {
         const char* ex = getenv("DFFT_EXCHANGE");
-        if (ex && std::string(ex) == "ipc") {  // hipIpc peer copies: no RCCL, ranks may share a GPU
-            CHECK_DFFT(dfft_comm_create_ipc(nprocs, me, &comm));
+        if (ex && (std::string(ex) == "ipc" || std::string(ex) == "ipc-async")) {  // hipIpc peer copies: no RCCL
+            CHECK_DFFT(dfft_comm_create_ipc(nprocs, me, std::string(ex) == "ipc-async" ? 1 : 0, &comm));
         } else {
             char id[128];
             if (me == 0) CHECK_DFFT(dfft_rccl_unique_id(id));

@@ -118,8 +118,10 @@ int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx,
  *         twin of the LOCAL communicator, i.e. the reference's MPI path with hipMemcpy instead of UCX (fft_mpi_3d_api.cpp:
  *         635-672).  Host-synchronising, so slower than RCCL for small messages; it also works with several processes sharing
  *         one GPU, which is how the multi-process path is tested on a single-GPU machine.  Plan creation and destruction are
- *         collective over the processes. */
-int dfft_comm_create_ipc(int total_devices, int global_idx, dfft_comm_t* comm);
+ *         collective over the processes.  async_exchange != 0: the barriers become flag words in IPC-shared fine-grained
+ *         memory, published and awaited by one-wave kernels on the plan's stream, so the exchange is stream-ordered like
+ *         RCCL's (nothing blocks the host, DFFT_PLAN_OVERLAP overlaps) while the data still moves by copy engines. */
+int dfft_comm_create_ipc(int total_devices, int global_idx, int async_exchange, dfft_comm_t* comm);
 int dfft_comm_destroy(dfft_comm_t comm);
 
 /* ---- memory ------------------------------------------------------------------------------------------------------------

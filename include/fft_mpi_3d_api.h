@@ -38,7 +38,8 @@ struct State {
     std::mutex               m;
     int                      total = 1, in_rank = 1, mpi_rank = 0, mpi_size = 1;
     bool                     have_id = false;
-    bool                     use_ipc = false;          // DFFT_EXCHANGE=ipc: hipIpc communicator instead of RCCL
+    bool                     use_ipc = false;          // DFFT_EXCHANGE=ipc | ipc-async: hipIpc communicator instead of RCCL
+    bool                     ipc_async = false;
     char                     rccl_id[128];
     dfft_comm_t              local = nullptr;          // single-process: shared by all device threads
     std::vector<dfft_comm_t> rccl;                     // multi-process: one communicator rank per local device
@@ -98,7 +99,8 @@ inline void fft_mpi_init(const longInt64* N, int iniDeviceNumInNode, MPI_Comm co
             DFFT_CHECK(dfft_comm_create_local(newDeviceCount, &s.local));
         } else {
             const char* ex = getenv("DFFT_EXCHANGE");
-            s.use_ipc = ex && (strcmp(ex, "ipc") == 0 || strcmp(ex, "IPC") == 0);
+            s.use_ipc = ex && (strcmp(ex, "ipc") == 0 || strcmp(ex, "ipc-async") == 0);
+            s.ipc_async = ex && strcmp(ex, "ipc-async") == 0;
             if (!s.use_ipc) {
                 // the reference's dead ENABLE_RCCL branch (fft_mpi_3d_api.cpp:29-37) made live
                 if (mpi_rank == 0) DFFT_CHECK(dfft_rccl_unique_id(s.rccl_id));
@@ -172,7 +174,7 @@ inline fft_mpi_3d_plan_p fft_mpi_plan_dft_c2c_3d(longInt64 n0, longInt64 n1, lon
         if (create) {
             // collective over every device of every rank: must not be called under the lock (the other device
             // threads of this process have to get in here too); slot devIdx belongs to this device thread alone
-            if (s.use_ipc) DFFT_CHECK(dfft_comm_create_ipc(totalDevCount, plan->globalDevIdx, &c));  // one device per process
+            if (s.use_ipc) DFFT_CHECK(dfft_comm_create_ipc(totalDevCount, plan->globalDevIdx, s.ipc_async ? 1 : 0, &c));
             else DFFT_CHECK(dfft_comm_create_rccl(id, totalDevCount, plan->globalDevIdx, &c));
             std::lock_guard<std::mutex> lk(s.m);
             s.rccl[devIdx] = c;

@@ -59,7 +59,7 @@ rank, P = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 n0, n1, n2 = N
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
-comm = api.Comm.ipc(P, rank)
+comm = api.Comm.ipc(P, rank, os.environ.get("DFFT_IPC_ASYNC") == "1")
 rng = np.random.default_rng(2024)
 x = rng.standard_normal(N) + 1j * rng.standard_normal(N)          # same array on every rank
 full = np.fft.fftn(x)
@@ -102,9 +102,13 @@ print("MP-OK", rank)
 '''
 
 
+@pytest.mark.parametrize("async_exchange", ["0", "1"], ids=["host-sync", "stream-ordered"])
 @pytest.mark.parametrize("N,world", [((64, 64, 32), 2), ((64, 64, 64), 4), ((25, 10, 16), 4), ((48, 40, 12), 3)])
-def test_one_process_per_slab_on_one_gpu(gpu, N, world):
-    outs = _launch(world, [sys.executable, "-c", WORKER], {"DFFT_N": "x".join(map(str, N))})
+def test_one_process_per_slab_on_one_gpu(gpu, N, world, async_exchange):
+    """async_exchange = 1: the exchange is enqueued on the plan's streams (flag words in IPC-shared memory, published and
+    awaited by one-wave kernels), i.e. the overlapped pipelines run with the same asynchrony they have on RCCL -- X passes
+    racing later sub-blocks' copies, Y+Z passes racing later parts -- across real process boundaries."""
+    outs = _launch(world, [sys.executable, "-c", WORKER], {"DFFT_N": "x".join(map(str, N)), "DFFT_IPC_ASYNC": async_exchange})
     for r, (o, _) in enumerate(outs):
         assert f"MP-OK {r}" in o
 
@@ -155,12 +159,13 @@ def test_heffte_protocol_front_end_multi_process(gpu, world, precision, tol):
     assert float(re.search(r"Time per run:\s*([0-9.eE+-]+)", out).group(1)) > 0
 
 
+@pytest.mark.parametrize("backend", ["ipc", "ipc-async"])
 @pytest.mark.parametrize("world,size", [(2, "64"), (4, "128")])
-def test_bench_multirank_flow_with_real_data(gpu, world, size):
+def test_bench_multirank_flow_with_real_data(gpu, world, size, backend):
     """bench.py --gpus W exactly as the driver launches it (one rank per process, torchrun-style environment), with the IPC
     exchange so that all ranks can share the one GPU: every check of the N > 1 report on real transforms."""
     outs = _launch(world, [sys.executable, str(ROOT / "bench.py"), "--gpus", str(world), "--size", size, "--steps", "4",
-                           "--warmup", "2", "--no-cpu-baseline"], {"DFFT_EXCHANGE": "ipc"})
+                           "--warmup", "2", "--no-cpu-baseline"], {"DFFT_EXCHANGE": backend})
     lines = [l for l in outs[0][0].splitlines() if l.startswith("{")]
     assert len(lines) == 1 and outs[0][0].strip() == lines[0]          # exactly one line on rank 0's stdout
     for o, _ in outs[1:]:
@@ -171,7 +176,7 @@ def test_bench_multirank_flow_with_real_data(gpu, world, size):
     assert d["overlap_result_bit_identical"] is True                    # the referee: overlapped == serial, bit for bit
     assert d["roundtrip_abs_error"] < 1e-11 and d["direct_dft_spot_check_rel_error"] < 1e-11
     assert set(d["stages_ms"]) == {"t0", "t1", "t2", "t3"} and set(d["pipeline_probe_ms_per_step"]) == {"overlapped", "serial"}
-    if d["pipeline"] == "serial":   # expected here: with a host-synchronising exchange the overlap cannot win
+    if d["pipeline"] == "serial":   # expected with the host-synchronising exchange: there the overlap cannot win
         assert "faster" in d["overlap_fallback"] and d["stages_ms"]["t2"] > 0
     else:
         assert d["stages_ms_without_overlap"]["t2"] > 0
