@@ -117,6 +117,7 @@ def main():
     P = world
     comm = None
     exchange_backend = os.environ.get("DFFT_EXCHANGE", "rccl").lower()
+    comm_fallback = None
     if P > 1:
         # control plane on gloo (barriers, max-reduce, id broadcast); the data plane (t2) is RCCL inside the library
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
@@ -129,8 +130,21 @@ def main():
         if not args.dry_run:
             # DFFT_EXCHANGE=ipc: hipIpc peer copies + rendezvous barriers instead of RCCL (also works with several ranks on
             # one GPU -- how this multi-rank path is exercised on a single-GPU box); default: RCCL over xGMI
-            comm = (api.Comm.ipc(P, rank, exchange_backend == "ipc-async") if exchange_backend in ("ipc", "ipc-async")
-                    else api.Comm.rccl(uid_bytes, P, rank))
+            if exchange_backend in ("ipc", "ipc-async"):
+                comm = api.Comm.ipc(P, rank, exchange_backend == "ipc-async")
+            else:
+                try:
+                    comm = api.Comm.rccl(uid_bytes, P, rank)
+                except Exception as e:  # RCCL unusable on this node: every rank falls back to the IPC communicator together
+                    comm, comm_fallback = None, f"RCCL communicator could not be created ({e})"
+                ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() != 1.0:
+                    if comm is not None:
+                        comm.destroy()
+                    comm_fallback = comm_fallback or "RCCL communicator could not be created on another rank"
+                    exchange_backend = "ipc-async"
+                    comm = api.Comm.ipc(P, rank, True)
     if args.dry_run:
         tot, inr, counts = api.fft_mpi_init(args.size, 1, mpi_size=P, mpi_rank=rank)
         lay = api.exchange_layout(*args.size, P, rank, api.FORWARD)
@@ -440,6 +454,8 @@ def main():
             elif referee_same is not None:
                 result["overlap_result_bit_identical"] = referee_same  # the referee's verdict before the fallback
             result["pipeline"] = "overlapped" if overlap else "serial"
+            if comm_fallback is not None:
+                result["exchange_fallback"] = comm_fallback
             if overlap_note is not None:
                 result["overlap_fallback"] = overlap_note
             if pipeline_probe_ms is not None:

@@ -159,6 +159,16 @@ def test_heffte_protocol_front_end_multi_process(gpu, world, precision, tol):
     assert float(re.search(r"Time per run:\s*([0-9.eE+-]+)", out).group(1)) > 0
 
 
+def test_bench_falls_back_to_ipc_when_rccl_cannot_start(gpu):
+    """Default exchange (RCCL) with two ranks on ONE GPU: RCCL refuses the duplicate device, every rank notices together and
+    the run continues on the stream-ordered IPC communicator -- the report says so."""
+    outs = _launch(2, [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "1",
+                       "--no-cpu-baseline"], {"DFFT_EXCHANGE": "rccl", "NCCL_DEBUG": "WARN"}, timeout=300)
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert "exchange_fallback" in d and "RCCL" in d["exchange_fallback"] and "ipc-async" in d["config"]["exchange"].lower()
+    assert d["overlap_result_bit_identical"] is True and d["direct_dft_spot_check_rel_error"] < 1e-11
+
+
 @pytest.mark.parametrize("backend", ["ipc", "ipc-async"])
 @pytest.mark.parametrize("world,size", [(2, "64"), (4, "128")])
 def test_bench_multirank_flow_with_real_data(gpu, world, size, backend):
