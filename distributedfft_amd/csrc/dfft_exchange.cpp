@@ -40,6 +40,9 @@ struct dfft_comm_s {
     std::vector<std::vector<unsigned long long*>> flag_regs;  // [registration][device]
     std::vector<unsigned long long>               seq;        // rounds issued per registration
     unsigned long long*                           err = nullptr;
+    std::vector<hipStream_t>                      peer_streams;  // one helper stream + event per peer for the pushes
+    std::vector<hipEvent_t>                       peer_events;
+    hipEvent_t                                    fork_event = nullptr;
     // rccl
     ncclComm_t nccl = nullptr;
     int        rank = 0;
@@ -361,12 +364,37 @@ int exchange_ipc_async(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hip
     }
     (void)hipGetLastError();
     if (ready.nsig || ready.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, ready, seq, c->err);
+    // every peer has its own xGMI link: the pushes to different peers go out on per-peer helper streams (fork after sync 1,
+    // join before sync 2) so that the copy engines drive all links at once instead of one after the other
+    if (c->peer_streams.empty()) {
+        c->peer_streams.assign(P, nullptr);
+        c->peer_events.assign(P, nullptr);
+        DFFT_HIP_TRY(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
+        for (int q = 0; q < P; ++q) {
+            if (q == me) continue;
+            DFFT_HIP_TRY(hipStreamCreateWithFlags(&c->peer_streams[q], hipStreamNonBlocking));
+            DFFT_HIP_TRY(hipEventCreateWithFlags(&c->peer_events[q], hipEventDisableTiming));
+        }
+    }
+    DFFT_HIP_TRY(hipEventRecord(c->fork_event, stream));
+    std::vector<char> used(P, 0);
     for (const Msg& m : r) {
         if (m.sc == 0) continue;
         void* dstbase = c->regs[x.slot][m.peer];
         if (!dstbase) return fail(DFFT_ECOMM, "ipc exchange: peer buffer is not mapped");
+        hipStream_t s = stream;
+        if (m.peer != me) {
+            s = c->peer_streams[m.peer];
+            if (!used[m.peer]) DFFT_HIP_TRY(hipStreamWaitEvent(s, c->fork_event, 0));
+            used[m.peer] = 1;
+        }
         DFFT_HIP_TRY(hipMemcpyAsync((char*)dstbase + (size_t)m.doff * eb, (const char*)x.sendbuf + (size_t)m.so * eb,
-                                    (size_t)m.sc * eb, hipMemcpyDeviceToDevice, stream));
+                                    (size_t)m.sc * eb, hipMemcpyDeviceToDevice, s));
+    }
+    for (int q = 0; q < P; ++q) {
+        if (!used[q]) continue;
+        DFFT_HIP_TRY(hipEventRecord(c->peer_events[q], c->peer_streams[q]));
+        DFFT_HIP_TRY(hipStreamWaitEvent(stream, c->peer_events[q], 0));
     }
     if (arrive.nsig || arrive.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, arrive, seq, c->err);
     DFFT_HIP_TRY(hipGetLastError());
@@ -526,6 +554,14 @@ int dfft_comm_destroy(dfft_comm_t comm) {
     if (!comm) return DFFT_OK;
     if (comm->kind == 1 && comm->nccl) ncclCommDestroy(comm->nccl);
     if (comm->err) (void)hipHostFree(comm->err);
+    for (hipStream_t s : comm->peer_streams)
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (hipEvent_t e : comm->peer_events)
+        if (e) (void)hipEventDestroy(e);
+    if (comm->fork_event) (void)hipEventDestroy(comm->fork_event);
     delete comm;
     return DFFT_OK;
 }
