@@ -192,3 +192,49 @@ def test_bench_multirank_flow_with_real_data(gpu, world, size, backend):
         assert d["stages_ms_without_overlap"]["t2"] > 0
     assert d["xgmi"]["pair_chunk_bytes"] == 16 * n ** 3 // world ** 2 and "ipc" in d["config"]["exchange"].lower()
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+
+
+STRESS_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from distributedfft_amd import api
+N = tuple(int(v) for v in os.environ["DFFT_N"].split("x"))
+rank, P = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+n0, n1, n2 = N
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+comm = api.Comm.ipc(P, rank, True)
+mc = api.get_max_data_count(n0, n1, n2, P, rank == P - 1)
+g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+a = torch.zeros(mc, dtype=torch.complex128, device=dev)
+cnt = (n0 // P) * n1 * n2
+a[:cnt] = torch.complex(torch.rand(cnt, generator=g, device=dev, dtype=torch.float64), torch.rand(cnt, generator=g, device=dev, dtype=torch.float64))
+for direction in (api.FORWARD, api.BACKWARD):
+    bs, bo = torch.zeros_like(a), torch.zeros_like(a)
+    ps = api.Plan(n0, n1, n2, a, bs, comm, rank, P, direction, api.PLAN_INPUT_FROM_IN)
+    po = api.Plan(n0, n1, n2, a, bo, comm, rank, P, direction, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP)
+    ps.execute(api.EXEC_NO_TIMING); ps.sync()
+    ref = bs.clone()
+    for rep in range(3):
+        for _ in range(12):                      # a deep queue of overlapped executes, no host synchronisation in between
+            po.execute(api.EXEC_NO_TIMING)
+        po.sync()
+        assert torch.equal(bo, ref), (direction, rep)
+    po.destroy(); ps.destroy()
+comm.destroy()
+print("STRESS-OK", rank)
+'''
+
+
+@pytest.mark.parametrize("N,world,parts,yparts", [((128, 128, 64), 4, "4", "2"), ((128, 64, 128), 2, "8", "4"),
+                                                   ((96, 96, 48), 4, "2", "1")])
+def test_overlapped_pipeline_stress_across_processes(gpu, N, world, parts, yparts):
+    """Back-to-back overlapped executes (12 deep, nothing synchronises the host in between) on the stream-ordered IPC
+    exchange, forward and backward, against the serial pipeline's result bit for bit: buffer reuse across consecutive
+    executes, send data still in flight when the next pass starts, early X passes -- the races an asynchronous exchange
+    can expose and a host-synchronising one cannot."""
+    outs = _launch(world, [sys.executable, "-c", STRESS_WORKER],
+                   {"DFFT_N": "x".join(map(str, N)), "DFFT_OVERLAP_PARTS": parts, "DFFT_OVERLAP_YPARTS": yparts})
+    for r, (o, _) in enumerate(outs):
+        assert f"STRESS-OK {r}" in o
