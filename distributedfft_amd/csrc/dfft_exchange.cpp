@@ -61,9 +61,7 @@ struct IpcSyncLists {
 __global__ void ipc_sync_kernel(IpcSyncLists L, unsigned long long seq, unsigned long long* err) {
     const int i = threadIdx.x;
     if (i < L.nsig) __hip_atomic_store(L.sig[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // the error is sticky: once a peer has failed to answer, later rounds do not wait for it again (a dead peer then costs
-    // one time-out, not one per queued round); dfft_plan_sync reports it
-    if (i < L.nwait && *(volatile unsigned long long*)err == 0) {
+    if (i < L.nwait) {
         const unsigned long long t0 = wall_clock64();  // 100 MHz
         while (__hip_atomic_load(L.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(16);
