@@ -157,6 +157,63 @@ def test_driver_cli_argument_check(native_lib):
     assert "distFFTOpt" in sh and "$2 $3 $4 1" in sh  # speedTest.sh:6 shape: <ranks> X Y Z -> ./distFFTOpt X Y Z 1
 
 
+def test_exchange_pieces_tile_the_buffers_and_pair_up(native_lib):
+    """What RCCL needs from the piece-wise exchange, checked on the message lists the library issues
+    (dfft_exchange_part_layout) for many decompositions, both directions: for every ordered pair (A -> B) A's send counts are
+    B's receive counts, in the same order; every rank's sends tile its local data exactly once (no overlap, no gap); every
+    rank's receives tile its re-slabbed data exactly once and stay inside getMaxDataCount."""
+    import random
+    from distributedfft_amd import api
+    rng = random.Random(20260921)
+    cases = [((16, 12, 8), 2, 3, 2), ((24, 24, 6), 4, 2, 3), ((10, 10, 4), 2, 2, 1), ((12, 9, 6), 3, 1, 1), ((64, 64, 8), 8, 3, 4),
+             ((25, 10, 16), 4, 2, 1), ((512, 512, 4), 8, 16, 2)]
+    for _ in range(25):
+        P = rng.choice([2, 3, 4, 5, 8])
+        n0, n1, n2 = rng.randrange(P, 40), rng.randrange(P, 40), rng.randrange(1, 9)
+        cases.append(((n0, n1, n2), P, rng.randrange(1, 6), rng.choice([1, 1, 2, 3])))
+    checked = 0
+    for (n0, n1, n2), P, pp, yk in cases:
+        xb, yb = -(-n0 // P), -(-n1 // P)
+        if n0 - (P - 1) * xb < 1 or n1 - (P - 1) * yb < 1:
+            continue  # decomposition leaves the last device empty (rejected at plan creation)
+        if yk > 1 and (n0 % P or n1 % P or (n1 // P) % yk):
+            yk = 1
+        nparts = -(-xb // pp)
+        for direction in (api.FORWARD, api.BACKWARD):
+            # the sequence of pieces execute_forward / execute_backward issue
+            if direction == api.FORWARD:
+                pieces = [(part, pp, -1) for part in range(nparts - 1)] + \
+                         ([(nparts - 1, pp, -1)] if yk == 1 else [(nparts - 1, pp, y) for y in range(yk)])
+            else:
+                pieces = [(0, xb, y) for y in range(yk - 1)] + [(part, pp, (yk - 1) if yk > 1 else -1) for part in range(nparts)]
+            sends = {r: [] for r in range(P)}
+            recvs = {r: [] for r in range(P)}
+            for part, cp, ycut in pieces:
+                per_rank = [api.exchange_part_layout(n0, n1, n2, P, r, cp, part, yk, ycut, direction) for r in range(P)]
+                for a in range(P):
+                    for b in range(P):
+                        a_to_b = [m[2] for m in per_rank[a] if m[0] == b]
+                        b_from_a = [m[4] for m in per_rank[b] if m[0] == a]
+                        assert a_to_b == b_from_a, ((n0, n1, n2), P, pp, yk, direction, part, ycut, a, b)
+                for r in range(P):
+                    sends[r] += [(m[1], m[2]) for m in per_rank[r] if m[2] > 0]
+                    recvs[r] += [(m[3], m[4]) for m in per_rank[r] if m[4] > 0]
+            for r in range(P):
+                xs = min(xb, n0 - r * xb)
+                ys = min(yb, n1 - r * yb)
+                own_before = xs * n1 * n2 if direction == api.FORWARD else n0 * ys * n2
+                own_after = n0 * ys * n2 if direction == api.FORWARD else xs * n1 * n2
+                cap = api.get_max_data_count(n0, n1, n2, P, r == P - 1)
+                for what, ivs, total in (("send", sends[r], own_before), ("recv", recvs[r], own_after)):
+                    ivs = sorted(ivs)
+                    assert sum(c for _, c in ivs) == total, (what, (n0, n1, n2), P, pp, yk, direction, r)
+                    for (o1, c1), (o2, _) in zip(ivs, ivs[1:]):
+                        assert o1 + c1 <= o2, (what, "overlap", (n0, n1, n2), P, pp, yk, direction, r)
+                    assert ivs[0][0] >= 0 and ivs[-1][0] + ivs[-1][1] <= cap, (what, "out of bounds", (n0, n1, n2), P, r)
+            checked += 1
+    assert checked >= 40
+
+
 def test_headline_kernels_do_not_spill():
     """The 512-point kernels of the benchmarked path (fp64, and fp32 on column pairs) must compile for gfx950 without
     scratch: a few extra live registers in the shared kernel template are enough to make the register-heavy variants spill,
