@@ -214,6 +214,26 @@ def test_exchange_pieces_tile_the_buffers_and_pair_up(native_lib):
     assert checked >= 40
 
 
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01/bench_512_fp64_P1.json is a verbatim bench.py line from the GPU box: the fields the driver's contract
+    names, the roofline object priced against the 8 TB/s HBM peak, and the CPU baseline timed on the same box."""
+    import json
+    d = json.loads((ROOT / "profiles" / "r01" / "bench_512_fp64_P1.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "GFlops/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["dtype"] == "f64"
+    assert d["data"] == "synthetic" and "512x512x512" in d["config"]["workload"] and d["vs_baseline"] is None
+    assert abs(d["value"] - 5.0 * 512 ** 3 * 27 * 1e-9 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3   # 5 N log2 N / t
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
+    assert 0.99 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05    # PMC bytes per launch vs algorithmic bytes
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "GFlops/s"
+    assert d["value"] / c["value"] > 100   # reported next to each other, not a target
+
+
 def test_headline_kernels_do_not_spill():
     """The 512-point kernels of the benchmarked path (fp64, and fp32 on column pairs) must compile for gfx950 without
     scratch: a few extra live registers in the shared kernel template are enough to make the register-heavy variants spill,
