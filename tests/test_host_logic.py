@@ -135,6 +135,32 @@ def test_product_path_fails_loudly_without_gpu(native_lib):
         api.Plan(8, 8, 8, torch.zeros(512, dtype=torch.complex128), None, None, 0, 1, api.FORWARD)
 
 
+def test_product_sources_never_touch_the_oracle_or_the_reference_tree():
+    """The oracle is test infrastructure: nothing under distributedfft_amd/ or include/ imports, includes, links or opens
+    anything under oracle/, and no product, bench or smoke source reads /root/reference at run time (only oracle/Makefile and
+    the fixture generator do, at build time in this container).  bench.py may call the oracle only in cpu_baseline()."""
+    import re
+    product = [p for p in list((ROOT / "distributedfft_amd").rglob("*")) + list((ROOT / "include").rglob("*"))
+               if p.is_file() and p.suffix in (".py", ".cpp", ".h", ".hip") and "lib" not in p.relative_to(ROOT).parts[1:2]]
+    assert len(product) > 15
+    for p in product:
+        text = p.read_text(errors="ignore")
+        code = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith(("//", "#", "*", "/*", '"""')))
+        assert not re.search(r"(from|import)\s+oracle|oracle/|slab_oracle", code), p
+        for m in re.finditer(r"/root/reference", code):   # citations live in comments and docstrings only
+            line = code[code.rfind("\n", 0, m.start()) + 1:code.find("\n", m.end())]
+            assert line.lstrip().startswith(("//", "*", "#")) or '"""' in text, (p, line)
+    bench = (ROOT / "bench.py").read_text()
+    assert bench.count("from oracle import") == 1 and bench.index("from oracle import") > bench.index("def cpu_baseline")
+    assert bench.index("from oracle import") < bench.index("def main")
+    # bench.py never names the reference tree in a string literal (only in a docstring); __graft_entry__.build() may look for
+    # it to build oracle/_ref in this container, smoke() may not
+    assert not re.search(r"""["']/root/reference""", bench)
+    entry = (ROOT / "__graft_entry__.py").read_text()
+    smoke_src = entry[entry.index("def smoke"):]
+    assert "/root/reference" not in smoke_src
+
+
 def test_python_mirror_of_init(native_lib):
     from distributedfft_amd import api
     tot, inr, counts = api.fft_mpi_init((512, 512, 512), 1, mpi_size=4, mpi_rank=2)
