@@ -163,7 +163,10 @@ def test_bench_falls_back_to_ipc_when_rccl_cannot_start(gpu):
     """Default exchange (RCCL) with two ranks on ONE GPU: RCCL refuses the duplicate device, every rank notices together and
     the run continues on the stream-ordered IPC communicator -- the report says so."""
     outs = _launch(2, [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "1",
-                       "--no-cpu-baseline"], {"DFFT_EXCHANGE": "rccl", "NCCL_DEBUG": "WARN"}, timeout=300)
+                       "--no-cpu-baseline"],
+                   {"DFFT_EXCHANGE": "rccl", "NCCL_DEBUG": "WARN",
+                    # one visible device (the first of whatever is visible now): both ranks land on it even on a multi-GPU box
+                    "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES", "0").split(",")[0]}, timeout=300)
     d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     assert "exchange_fallback" in d and "RCCL" in d["exchange_fallback"] and "ipc-async" in d["config"]["exchange"].lower()
     assert d["overlap_result_bit_identical"] is True and d["direct_dft_spot_check_rel_error"] < 1e-11
