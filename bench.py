@@ -24,8 +24,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-HBM_COPY_CEILING_GBS = 6290.0
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+# best 2 GiB -> 2 GiB copy measured on this GPU model (profiles/r02/README.md: 5.95 TB/s over 280 copy configurations; the
+# guide's 6.29 TB/s float4 figure is reached only by working sets that partly live in the Infinity Cache)
+HBM_COPY_CEILING_GBS = 5950.0
 
 
 def parse_size(s: str):
@@ -36,32 +38,85 @@ def parse_size(s: str):
     return tuple(p)
 
 
-def cpu_baseline(sample_n: int = 256):
-    """CPU leg (rank 0, N=1 only): the reference's bundled heFFTe 2.1.0 stock backend (oracle/_ref/speed3d_c2c, built from
-    /root/reference sources by oracle/Makefile) on a bounded sample; falls back to timing the C restatement (a port)."""
-    cores = os.cpu_count() or 1
-    ranks = 1
-    while ranks * 2 <= min(cores, 64):
-        ranks *= 2
+def physical_cores() -> int:
+    """Physical cores of this host (unique (socket, core) pairs in /proc/cpuinfo); hardware threads if that cannot be read."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            pairs.add((phys, core))
+        if pairs:
+            return len(pairs)
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def _heffte_stock(sample_n: int, ranks: int, timeout: float):
+    """One run of the reference's bundled heFFTe 2.1.0 stock-CPU benchmark (oracle/_ref/speed3d_c2c, built from the sources
+    under /root/reference by oracle/Makefile): (GFlops/s, 'Time per run' line) or None."""
     exe = ROOT / "oracle" / "_ref" / "speed3d_c2c"
     mpirun = Path("/opt/conda/bin/mpirun")
-    flops = 5.0 * sample_n ** 3 * math.log2(sample_n ** 3) * 1e-9
-    if exe.exists() and mpirun.exists():
-        try:
-            env = dict(os.environ)
-            env["LD_LIBRARY_PATH"] = str(exe.parent / "mpilib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    if not (exe.exists() and mpirun.exists()):
+        return None
+    try:
+        env = dict(os.environ)
+        env["LD_LIBRARY_PATH"] = str(exe.parent / "mpilib") + ":" + env.get("LD_LIBRARY_PATH", "")
+        r = subprocess.run([str(mpirun), "--oversubscribe", "-np", str(ranks), str(exe), "stock", "double", str(sample_n), str(sample_n),
+                            str(sample_n), "-slabs", "-p2p_pl"], capture_output=True, text=True, timeout=timeout, env=env,
+                           cwd="/tmp")
+        if r.returncode != 0:  # older launchers do not know --oversubscribe
             r = subprocess.run([str(mpirun), "-np", str(ranks), str(exe), "stock", "double", str(sample_n), str(sample_n),
-                                str(sample_n), "-slabs", "-p2p_pl"], capture_output=True, text=True, timeout=240, env=env,
+                                str(sample_n), "-slabs", "-p2p_pl"], capture_output=True, text=True, timeout=timeout, env=env,
                                cwd="/tmp")
-            perf = [l for l in r.stdout.splitlines() if l.strip().startswith("Performance:")]
-            tim = [l for l in r.stdout.splitlines() if l.strip().startswith("Time per run:")]
-            if r.returncode == 0 and perf:
-                return {"value": float(perf[0].split()[1]), "unit": "GFlops/s", "cores": ranks, "kind": "reference",
-                        "sample": f"heFFTe 2.1.0 stock backend (bundled with the reference), {sample_n}^3 fp64 C2C, "
-                                  f"mpirun -np {ranks} -slabs -p2p_pl, {tim[0].strip() if tim else ''} "
-                                  f"(host has {cores} hardware threads)"}
-        except Exception:
-            pass
+        perf = [l for l in r.stdout.splitlines() if l.strip().startswith("Performance:")]
+        tim = [l for l in r.stdout.splitlines() if l.strip().startswith("Time per run:")]
+        if r.returncode == 0 and perf:
+            return float(perf[0].split()[1]), (tim[0].strip() if tim else "")
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline():
+    """CPU leg (rank 0, N=1 only): the reference's bundled heFFTe stock backend on the metric's own configuration
+    (512^3 fp64 C2C), 256^3 as a second, smaller sample.  MPI ranks (= cores used, stated in the line): 16 -- on the GPU
+    box's host (2 x EPYC 9575F, 128 cores) the stock backend gets SLOWER with more ranks at this size (512^3: 14.9 GFlop/s
+    on 16 ranks, 10.5 on 32, 8.5 on 64, > 200 s on 128; profiles/r02/experiments/cpu_baseline_rank_sweep.log), so the
+    fastest measured launch is the one reported, and it keeps the CPU work to ~15 s.  DFFT_CPU_BASELINE_RANKS overrides.
+    Falls back to timing the C restatement of the pipeline (a port) when the reference build is absent."""
+    threads = os.cpu_count() or 1
+    cores = physical_cores()
+    want = int(os.environ.get("DFFT_CPU_BASELINE_RANKS", "16"))
+    ranks = 1
+    while ranks * 2 <= min(cores, max(want, 1)):
+        ranks *= 2
+    t0 = time.perf_counter()
+    main_run = _heffte_stock(512, ranks, 150.0)
+    t_main = time.perf_counter() - t0
+    if main_run is not None:
+        out = {"value": main_run[0], "unit": "GFlops/s", "cores": ranks, "kind": "reference",
+               "sample": f"heFFTe 2.1.0 stock backend (bundled with the reference), 512^3 fp64 C2C (the metric's configuration), "
+                         f"mpirun -np {ranks} -slabs -p2p_pl, {main_run[1]}, whole benchmark {t_main:.1f} s "
+                         f"(host: {cores} physical cores, {threads} hardware threads)"}
+        small = _heffte_stock(256, ranks, 60.0)
+        if small is not None:
+            out["second_sample"] = {"value": small[0], "unit": "GFlops/s", "sample": f"256^3 fp64 C2C, same launch, {small[1]}"}
+        return out
+    small = _heffte_stock(256, ranks, 120.0)
+    if small is not None:
+        return {"value": small[0], "unit": "GFlops/s", "cores": ranks, "kind": "reference",
+                "sample": f"heFFTe 2.1.0 stock backend (bundled with the reference), 256^3 fp64 C2C (512^3 did not finish in "
+                          f"150 s), mpirun -np {ranks} -slabs -p2p_pl, {small[1]} (host: {cores} physical cores, {threads} "
+                          f"hardware threads)"}
     from oracle import slab_oracle as so
     n = 128
     x = so.random_input((n, n, n), seed=3)
@@ -70,6 +125,37 @@ def cpu_baseline(sample_n: int = 256):
     dt = time.perf_counter() - t
     return {"value": 5.0 * n ** 3 * math.log2(n ** 3) * 1e-9 / dt, "unit": "GFlops/s", "cores": 1, "kind": "port",
             "sample": f"oracle/slab_oracle.c (scalar C restatement), {n}^3 fp64 forward, 1 thread, {dt:.3f} s"}
+
+
+def library_sha256() -> str | None:
+    """sha256 of the native library this process loaded: ties profiles/hbm_traffic.json to the build it was measured on."""
+    try:
+        import hashlib
+        from distributedfft_amd import _lib
+        path = Path(os.environ.get("DFFT_LIB", str(_lib.LIB_PATH)))
+        return hashlib.sha256(path.read_bytes()).hexdigest()
+    except Exception:
+        return None
+
+
+def measured_traffic(key: str, kernel: str):
+    """(bytes per launch, source) from profiles/hbm_traffic.json when it was measured on the library build that is loaded
+    now, else (None, reason)."""
+    tfile = ROOT / "profiles" / "hbm_traffic.json"
+    if not tfile.exists():
+        return None, "profiles/hbm_traffic.json not present"
+    try:
+        tr = json.loads(tfile.read_text())
+        ent = tr.get(key, {})
+        if kernel not in ent:
+            return None, f"no PMC entry for {kernel} / {key}"
+        want, have = ent.get("library_sha256"), library_sha256()
+        if want is None or have is None or want != have:
+            return None, (f"PMC summary {ent.get('source', 'profiles/')} was taken on another build of the library "
+                          f"(sha256 {str(want)[:12]} vs loaded {str(have)[:12]}): re-run tools/profile_bench.sh")
+        return ent[kernel]["hbm_bytes_per_launch"], ent.get("source", "profiles/")
+    except Exception as e:
+        return None, f"profiles/hbm_traffic.json unreadable: {e}"
 
 
 def main():
@@ -118,9 +204,28 @@ def main():
     comm = None
     exchange_backend = os.environ.get("DFFT_EXCHANGE", "rccl").lower()
     comm_fallback = None
+    def note(msg):  # launch diagnostics, one line per rank, never on stdout
+        print(f"[bench rank {rank}/{world}] {msg}", file=sys.stderr, flush=True)
+
     if P > 1:
         # control plane on gloo (barriers, max-reduce, id broadcast); the data plane (t2) is RCCL inside the library
         dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+        if not args.dry_run and not stub_mode:
+            # --gpus N means N distinct GPUs: ranks sharing a device would time something else under the same name.
+            # (DFFT_BENCH_ALLOW_SHARED_GPU=1: the single-GPU functional tests of this flow, IPC back-ends only.)
+            prop = torch.cuda.get_device_properties(dev)
+            ident = str(getattr(prop, "uuid", "")) or f"{getattr(prop, 'pci_bus_id', '?')}:{getattr(prop, 'pci_device_id', '?')}"
+            mine = f"{os.uname().nodename}/{ident}/ordinal{torch.cuda.current_device()}"
+            idents = [None] * world
+            dist.all_gather_object(idents, mine)
+            note(f"device {torch.cuda.current_device()} of {torch.cuda.device_count()} visible: {prop.name} [{mine}]")
+            if len(set(idents)) < world and os.environ.get("DFFT_BENCH_ALLOW_SHARED_GPU", "0") != "1":
+                if rank == 0:
+                    print(f"bench.py --gpus {world}: only {len(set(idents))} distinct device(s) behind {world} ranks: {idents}",
+                          file=sys.stderr, flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                raise SystemExit(4)
         uid = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             raw = bytes(range(128)) if args.dry_run else api.Comm.rccl_unique_id()
@@ -133,10 +238,32 @@ def main():
             if exchange_backend in ("ipc", "ipc-async"):
                 comm = api.Comm.ipc(P, rank, exchange_backend == "ipc-async")
             else:
+                # ncclCommInitRank is a blocking collective: a rank that never arrives would hang the others forever, and
+                # a hung rank can never reach the agreement below -- a watchdog turns that into a loud, non-zero exit
+                import threading
+                limit = float(os.environ.get("DFFT_RCCL_INIT_TIMEOUT_S", "180"))
+
+                def _abort():
+                    print(f"[bench rank {rank}/{world}] ncclCommInitRank did not return within {limit:.0f} s "
+                          f"(DFFT_RCCL_INIT_TIMEOUT_S): aborting", file=sys.stderr, flush=True)
+                    os._exit(5)
+                dog = threading.Timer(limit, _abort)
+                dog.daemon = True
+                dog.start()
                 try:
                     comm = api.Comm.rccl(uid_bytes, P, rank)
+                    info = comm.info()
+                    note(f"ncclCommInitRank ok: RCCL reports {info['size']} ranks, this is rank {info['rank']} on device "
+                         f"{info['device']}")
+                    if info["size"] != P or info["rank"] != rank:
+                        raise RuntimeError(f"RCCL communicator has {info['size']} ranks / rank {info['rank']}, expected {P} / {rank}")
                 except Exception as e:  # RCCL unusable on this node: every rank falls back to the IPC communicator together
+                    note(f"ncclCommInitRank FAILED: {e}")
+                    if comm is not None:
+                        comm.destroy()
                     comm, comm_fallback = None, f"RCCL communicator could not be created ({e})"
+                finally:
+                    dog.cancel()
                 ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if ok.item() != 1.0:
@@ -144,6 +271,8 @@ def main():
                         comm.destroy()
                     comm_fallback = comm_fallback or "RCCL communicator could not be created on another rank"
                     exchange_backend = "ipc-async"
+                    note("EXCHANGE FALLBACK: RCCL is not usable on every rank -- this run uses the stream-ordered hipIpc "
+                         "communicator instead (config.exchange and exchange_fallback in the JSON line say so)")
                     comm = api.Comm.ipc(P, rank, True)
     if args.dry_run:
         tot, inr, counts = api.fft_mpi_init(args.size, 1, mpi_size=P, mpi_rank=rank)
@@ -231,6 +360,12 @@ def main():
                                     f"{pipeline_probe_ms['overlapped']} ms per step): timed the serial pipeline")
         except Exception as e:  # never lose the headline number to the overlap machinery
             overlap_note = f"overlap set-up failed ({e}): timed the serial pipeline instead"
+        # every rank must take the same branch below (plan creation / destruction are collectives on the IPC communicators
+        # and the two pipelines issue different message sequences): agree on the decision
+        agree = torch.tensor([0.0 if overlap_note is None else 1.0], dtype=torch.float64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX)
+        if agree.item() != 0.0 and overlap_note is None:
+            overlap_note = "another rank left the overlapped pipeline: timed the serial pipeline instead"
         if overlap_note is not None:
             overlap = False
             if plan_s is None:
@@ -383,16 +518,12 @@ def main():
                                  "as_one_stage_GB/s": round(zy / 2, 1),  # t0 read once + written once
                                  "as_one_stage_frac_of_peak": round(zy / 2 / HBM_PEAK_GBS, 4)},
                     "local_pipeline": {"bytes": 2 * local_bytes, "GB/s": round(2 * local_bytes / float(stage[0] + stage[1] + stage[3]) / 1e9, 1)}}
-            tfile = ROOT / "profiles" / "hbm_traffic.json"
-            if tfile.exists():
-                try:
-                    tr = json.loads(tfile.read_text())
-                    key = f"{n0}x{n1}x{n2}_{args.precision}_P{P}"
-                    if key in tr and names[2] in tr[key]:
-                        roof["traffic"] = tr[key][names[2]]["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = tr[key].get("source", "profiles/")
-                except Exception:
-                    pass
+            key = f"{n0}x{n1}x{n2}_{args.precision}_P{P}"
+            roof["traffic"], roof["traffic_source"] = measured_traffic(key, names[2])
+            zt, zsrc = measured_traffic(key, "t0 chunk kernels (Z rows + Y columns)")
+            roof["zy_stage"]["traffic"] = zt  # fabric bytes of the whole t0 stage (all chunk launches of one execute)
+            if zt is None:
+                roof["zy_stage"]["traffic_note"] = zsrc
         if kern is not None:
             k = int(np.argmax(kern))
             ach = local_bytes / kern[k] / 1e9
@@ -404,16 +535,7 @@ def main():
                     "all_kernels": {n: {"ms": round(float(t_) * 1e3, 4), "GB/s": round(local_bytes / t_ / 1e9, 1)}
                                     for n, t_ in zip(names, kern)},
                     "local_pipeline": {"bytes": 2 * local_bytes, "GB/s": round(2 * local_bytes / float(stage[0] + stage[1] + stage[3]) / 1e9, 1)}}
-            tfile = ROOT / "profiles" / "hbm_traffic.json"
-            if tfile.exists():
-                try:
-                    tr = json.loads(tfile.read_text())
-                    key = f"{n0}x{n1}x{n2}_{args.precision}_P{P}"
-                    if key in tr and names[k] in tr[key]:
-                        roof["traffic"] = tr[key][names[k]]["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = tr[key].get("source", "profiles/")
-                except Exception:
-                    pass
+            roof["traffic"], roof["traffic_source"] = measured_traffic(f"{n0}x{n1}x{n2}_{args.precision}_P{P}", names[k])
         total_stage = float(sum(stage))
         result = {
             "metric": "GFlops/s forward 3D C2C (5 N log2 N), 512^3 fp64" if args.size == (512, 512, 512) and args.precision == "fp64"

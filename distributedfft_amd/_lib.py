@@ -43,6 +43,7 @@ SIGNATURES = {
     "dfft_rccl_unique_id": (C.c_int, [C.c_char_p]),
     "dfft_comm_create_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_VP)]),
     "dfft_comm_create_ipc": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "dfft_comm_info": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfft_comm_destroy": (C.c_int, [_VP]),
     "dfft_alloc": (_VP, [_LL, C.c_int, C.c_int]),
     "dfft_free": (C.c_int, [_VP, C.c_int]),

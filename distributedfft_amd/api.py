@@ -120,6 +120,12 @@ class Comm:
                 "dfft_comm_create_ipc")
         return Comm(h, "ipc-async" if async_exchange else "ipc", total_devices)
 
+    def info(self) -> dict:
+        """{'kind', 'size', 'rank', 'device'} as the transport reports them (dfft_comm_info)."""
+        k, s, r, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.check(L.load().dfft_comm_info(self.handle, C.byref(k), C.byref(s), C.byref(r), C.byref(d)), "dfft_comm_info")
+        return {"kind": ("local", "rccl", "ipc", "ipc-async")[k.value], "size": s.value, "rank": r.value, "device": d.value}
+
     def destroy(self):
         if self.handle:
             L.load().dfft_comm_destroy(self.handle)

@@ -96,9 +96,27 @@ int dfft_boot_init(void) {
         sockaddr_in sa;
         std::memset(&sa, 0, sizeof(sa));
         sa.sin_family = AF_INET;
-        sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        // listen on the rendezvous address only (loopback unless DFFT_MASTER_ADDR / MASTER_ADDR names a local interface):
+        // the hello is unauthenticated and the channel carries the RCCL id and hipIpc handles, so it must not be reachable
+        // from interfaces the job does not use.  An address that is not local falls back to loopback.
+        if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1) {
+            sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+            addrinfo hints, *res = nullptr;  // a host name: listen where the peers will resolve it to
+            std::memset(&hints, 0, sizeof(hints));
+            hints.ai_family = AF_INET;
+            hints.ai_socktype = SOCK_STREAM;
+            if (getaddrinfo(addr, nullptr, &hints, &res) == 0 && res) {
+                sa.sin_addr = ((sockaddr_in*)res->ai_addr)->sin_addr;
+                freeaddrinfo(res);
+            }
+        }
         sa.sin_port = htons((uint16_t)portno);
-        if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, g.size) != 0) {
+        bool bound = ::bind(ls, (sockaddr*)&sa, sizeof(sa)) == 0;
+        if (!bound && sa.sin_addr.s_addr != htonl(INADDR_LOOPBACK)) {
+            sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+            bound = ::bind(ls, (sockaddr*)&sa, sizeof(sa)) == 0;
+        }
+        if (!bound || ::listen(ls, g.size) != 0) {
             ::close(ls);
             return fail(DFFT_ECOMM, std::string("dfft_boot_init: bind/listen on port ") + std::to_string(portno) + ": " +
                                         strerror(errno));

@@ -52,25 +52,34 @@ struct dfft_comm_s {
 namespace {
 // Cross-process, stream-ordered synchronisation of the asynchronous IPC exchange: lane i publishes `seq` to sig[i] (a flag
 // word in a peer's memory), then lane i waits until wait[i] (a flag word in this device's memory) has reached `seq`.
-// Bounded: after ~20 s the kernel gives up and reports through the pinned `err` word instead of hanging the device.
+// Bounded: after DFFT_IPC_TIMEOUT_S seconds (default 20) the kernel gives up and reports through the pinned `err` word
+// instead of hanging the device.
 struct IpcSyncLists {
     unsigned long long*       sig[64];
     const unsigned long long* wait[64];
     int                       nsig, nwait;
 };
-__global__ void ipc_sync_kernel(IpcSyncLists L, unsigned long long seq, unsigned long long* err) {
+__global__ void ipc_sync_kernel(IpcSyncLists L, unsigned long long seq, unsigned long long* err, unsigned long long limit_ticks) {
     const int i = threadIdx.x;
     if (i < L.nsig) __hip_atomic_store(L.sig[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i < L.nwait) {
         const unsigned long long t0 = wall_clock64();  // 100 MHz
         while (__hip_atomic_load(L.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(16);
-            if (wall_clock64() - t0 > 2000000000ull) {
+            if (wall_clock64() - t0 > limit_ticks) {
                 *err = seq;
                 break;
             }
         }
     }
+}
+unsigned long long ipc_timeout_ticks() {  // wall_clock64 runs at 100 MHz
+    static const unsigned long long t = [] {
+        const char* e = std::getenv("DFFT_IPC_TIMEOUT_S");
+        const double s = e && atof(e) > 0 ? atof(e) : 20.0;
+        return (unsigned long long)(s * 1e8);
+    }();
+    return t;
 }
 }  // namespace
 
@@ -80,7 +89,7 @@ int comm_kind(dfft_comm_t c) { return c->kind; }
 bool comm_is_async(dfft_comm_t c) { return c->kind == 1 || c->kind == 3; }
 int comm_check(dfft_comm_t c) {
     if (c && c->kind == 3 && c->err && *(volatile unsigned long long*)c->err != 0)
-        return fail(DFFT_ECOMM, "ipc exchange: a peer did not answer within 20 s (round " + std::to_string(*c->err) + ")");
+        return fail(DFFT_ECOMM, "ipc exchange: a peer did not answer within the time limit (DFFT_IPC_TIMEOUT_S, default 20 s; round " + std::to_string(*c->err) + ")");
     return DFFT_OK;
 }
 int comm_size(dfft_comm_t c) { return c->P; }
@@ -304,7 +313,10 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
     const size_t eb = elem_bytes(x.dtype);
     // every device has finished producing its send buffer and consuming its receive buffer
     DFFT_HIP_TRY(hipStreamSynchronize(stream));
-    comm_thread_barrier(c);
+    {
+        const int brc = comm_thread_barrier(c);  // IPC: the TCP rendezvous -- a dead peer must not let this rank push on
+        if (brc) return brc;
+    }
     int mydev = 0;
     DFFT_HIP_TRY(hipGetDevice(&mydev));
     const size_t nm = r.size();
@@ -329,8 +341,7 @@ int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStre
         else DFFT_HIP_TRY(hipMemcpyPeerAsync(dst, dstdev, src, mydev, bytes, stream));
     }
     DFFT_HIP_TRY(hipStreamSynchronize(stream));
-    comm_thread_barrier(c);  // all incoming chunks have landed
-    return DFFT_OK;
+    return comm_thread_barrier(c);  // all incoming chunks have landed
 }
 
 // Asynchronous IPC exchange (kind 3): everything is enqueued on `stream`, nothing blocks the host.
@@ -363,7 +374,7 @@ int exchange_ipc_async(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hip
         }
     }
     (void)hipGetLastError();
-    if (ready.nsig || ready.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, ready, seq, c->err);
+    if (ready.nsig || ready.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, ready, seq, c->err, ipc_timeout_ticks());
     // every peer has its own xGMI link: the pushes to different peers go out on per-peer helper streams (fork after sync 1,
     // join before sync 2) so that the copy engines drive all links at once instead of one after the other
     if (c->peer_streams.empty()) {
@@ -396,7 +407,7 @@ int exchange_ipc_async(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hip
         DFFT_HIP_TRY(hipEventRecord(c->peer_events[q], c->peer_streams[q]));
         DFFT_HIP_TRY(hipStreamWaitEvent(stream, c->peer_events[q], 0));
     }
-    if (arrive.nsig || arrive.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, arrive, seq, c->err);
+    if (arrive.nsig || arrive.nwait) hipLaunchKernelGGL(ipc_sync_kernel, dim3(1), dim3(64), 0, stream, arrive, seq, c->err, ipc_timeout_ticks());
     DFFT_HIP_TRY(hipGetLastError());
     return DFFT_OK;
 }
@@ -429,13 +440,19 @@ int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStrea
         for (const Msg& m : r) {
             if (m.peer == to && m.sc > 0) {
                 rc = ncclSend((const char*)x.sendbuf + (size_t)m.so * eb, (size_t)m.sc * 2, ty, to, c->nccl, stream);
-                if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(rc));
+                if (rc != ncclSuccess) {
+                    (void)ncclGroupEnd();  // never leave the group open behind an error
+                    return fail(DFFT_ERCCL, std::string("ncclSend: ") + ncclGetErrorString(rc));
+                }
             }
         }
         for (const Msg& m : r) {
             if (m.peer == from && m.rc > 0) {
                 rc = ncclRecv((char*)x.recvbuf + (size_t)m.ro * eb, (size_t)m.rc * 2, ty, from, c->nccl, stream);
-                if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(rc));
+                if (rc != ncclSuccess) {
+                    (void)ncclGroupEnd();
+                    return fail(DFFT_ERCCL, std::string("ncclRecv: ") + ncclGetErrorString(rc));
+                }
             }
         }
     }
@@ -547,6 +564,22 @@ int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx,
         return fail(DFFT_ERCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
     }
     *comm = c;
+    return DFFT_OK;
+}
+
+int dfft_comm_info(dfft_comm_t comm, int* kind, int* size, int* rank, int* device) {
+    if (!comm) return fail(DFFT_EINVAL, "dfft_comm_info: null communicator");
+    int sz = comm->P, rk = comm->rank, dev = comm->kind == 0 ? -1 : comm->device;
+    if (comm->kind == 1) {
+        ncclResult_t r = ncclCommCount(comm->nccl, &sz);
+        if (r == ncclSuccess) r = ncclCommUserRank(comm->nccl, &rk);
+        if (r == ncclSuccess) r = ncclCommCuDevice(comm->nccl, &dev);
+        if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("dfft_comm_info: ") + ncclGetErrorString(r));
+    }
+    if (kind) *kind = comm->kind;
+    if (size) *size = sz;
+    if (rank) *rank = rk;
+    if (device) *device = dev;
     return DFFT_OK;
 }
 

@@ -3,6 +3,8 @@
 // The fused pipeline never launches pack/transpose (the FFT kernels' address maps do that work); they exist so the
 // reference's stage structure (t1 = pack, t3 = transpose + FFT) can be reproduced and timed stage by stage
 // (DFFT_FUSE=0), and as independent checks of the fused address maps.
+#include <mutex>
+
 #include "dfft_kernels.h"
 #include "dfft_plans.h"
 
@@ -108,12 +110,22 @@ hipError_t launch_transpose(int dtype, const void* in, void* out, long long rows
     (void)hipGetLastError();
     if (dtype == F64) {
         constexpr int lds = 64 * 65 * (int)sizeof(double2);  // 66,560 B > the 64 KiB default cap
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_tile_kernel<double2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
+        // function attributes are per device: with the thread-per-GPU communicator every device needs its own opt-in to
+        // more than 64 KiB of dynamic LDS (one flag per device, set under a lock; the call itself is cheap and idempotent)
+        static std::mutex    attr_mutex;
+        static bool          attr_set[64] = {false};
+        int                  dev = 0;
+        hipError_t           e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        {
+            std::lock_guard<std::mutex> lk(attr_mutex);
+            if (!attr_set[dev]) {
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(transpose_tile_kernel<double2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return e;
+                attr_set[dev] = true;
+            }
         }
         hipLaunchKernelGGL((transpose_tile_kernel<double2>), dim3((unsigned)grid), dim3(256), lds, stream, (const double2*)in, (double2*)out, rows, cols, tiles_c);
     } else if (dtype == F32) {

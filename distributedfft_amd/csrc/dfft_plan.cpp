@@ -929,6 +929,12 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
              : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
                                                : execute_backward(plan, sync);
     if (rc) return rc;
+    // host-synchronised executes have drained the stream: an asynchronous exchange that timed out on a dead or slow peer
+    // must not let the caller print timings / use results (the reference-named wrapper always executes this way)
+    if (sync && plan->comm) {
+        rc = comm_check(plan->comm);
+        if (rc) return rc;
+    }
     if ((exec_flags & DFFT_EXEC_PRINT) && plan->direction == DFFT_FORWARD) {
         double t[4];
         rc = dfft_stage_times(plan, t);
@@ -949,6 +955,10 @@ int dfft_plan_sync(dfft_plan_t plan) {
 int dfft_stage_times(dfft_plan_t plan, double t[4]) {
     if (!plan || !t) return fail(DFFT_EINVAL, "dfft_stage_times: bad arguments");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    if (plan->comm) {
+        const int rc = comm_check(plan->comm);
+        if (rc) return rc;
+    }
     if (!plan->timed) return fail(DFFT_EINVAL, "dfft_stage_times: the last execute ran with DFFT_EXEC_NO_TIMING");
     if (plan->host_timed) {
         for (int i = 0; i < 4; ++i) t[i] = plan->host_t[i];

@@ -122,6 +122,12 @@ int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx,
  *         memory, published and awaited by one-wave kernels on the plan's stream, so the exchange is stream-ordered like
  *         RCCL's (nothing blocks the host, DFFT_PLAN_OVERLAP overlaps) while the data still moves by copy engines. */
 int dfft_comm_create_ipc(int total_devices, int global_idx, int async_exchange, dfft_comm_t* comm);
+/* What a communicator actually is, as the transport reports it (launch diagnostics: a multi-GPU benchmark must be able to
+ * prove which back-end ran and over how many ranks).  kind: 0 LOCAL, 1 RCCL, 2 IPC (host-synchronised), 3 IPC (stream-ordered);
+ * size/rank: for RCCL the values of ncclCommCount / ncclCommUserRank (not the arguments the caller passed), otherwise the
+ * creation arguments; device: HIP device ordinal the communicator is bound to (ncclCommCuDevice for RCCL, -1 for LOCAL).
+ * Any output pointer may be NULL.  (The reference has no counterpart: MPI_Comm_size/rank, fftSpeed3d_c2c.cpp:20-21.) */
+int dfft_comm_info(dfft_comm_t comm, int* kind, int* size, int* rank, int* device);
 int dfft_comm_destroy(dfft_comm_t comm);
 
 /* ---- memory ------------------------------------------------------------------------------------------------------------

@@ -26,12 +26,13 @@ def _free_port():
     return p
 
 
-def _launch(world, argv, extra_env=None, timeout=600):
+def _launch(world, argv, extra_env=None, timeout=600, expect_rc=0):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), DFFT_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), DFFT_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   DFFT_BENCH_ALLOW_SHARED_GPU="1")  # these tests put several ranks on one GPU on purpose
         env.pop("DFFT_MASTER_PORT", None)
         if extra_env:
             env.update(extra_env)
@@ -45,8 +46,52 @@ def _launch(world, argv, extra_env=None, timeout=600):
                 q.kill()
             raise
     for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, (o + e)[-3000:]
+        assert p.returncode == expect_rc, (o + e)[-3000:]
     return outs
+
+
+def test_bench_refuses_ranks_that_share_a_device(gpu):
+    """`bench.py --gpus 2` with both ranks on ONE device exits non-zero on every rank (a number measured that way would carry
+    the name of a 2-GPU run); the functional tests below opt out explicitly with DFFT_BENCH_ALLOW_SHARED_GPU=1."""
+    outs = _launch(2, [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--size", "64", "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline"],
+                   {"DFFT_EXCHANGE": "ipc-async", "DFFT_BENCH_ALLOW_SHARED_GPU": "0",
+                    "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES", "0").split(",")[0]}, timeout=300, expect_rc=4)
+    assert "distinct device" in outs[0][1] and not any(l.startswith("{") for l in outs[0][0].splitlines())
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_bench_two_gpus_on_rccl(gpu):
+    """The north-star exchange on real links: `bench.py --gpus 2` as the driver launches it, RCCL grouped send/recv between
+    two devices.  The report must say RCCL ran (no fall-back), the overlapped pipeline must match the serial one bit for bit,
+    and the result must pass the direct-DFT spot check over both ranks' inputs."""
+    outs = _launch(2, [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--size", "256", "--steps", "5", "--warmup", "2",
+                       "--no-cpu-baseline"], {"DFFT_EXCHANGE": "rccl", "DFFT_BENCH_ALLOW_SHARED_GPU": "0"}, timeout=600)
+    d = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and "RCCL" in d["config"]["exchange"] and "exchange_fallback" not in d
+    assert d["overlap_result_bit_identical"] is True
+    assert d["roundtrip_abs_error"] < 1e-11 and d["direct_dft_spot_check_rel_error"] < 1e-11
+    for r, (_, e) in enumerate(outs):
+        assert "ncclCommInitRank ok: RCCL reports 2 ranks" in e, e[-2000:]
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_speedtest_two_ranks_on_rccl(gpu):
+    """`sh speedTest.sh 2 64 64 64` (the reference's CLI, speedTest.sh:1-17) on the default RCCL exchange: the driver's own
+    report block with a sane error."""
+    import re
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DFFT_MASTER_PORT=str(_free_port()))
+    env.pop("DFFT_EXCHANGE", None)
+    r = subprocess.run(["sh", str(ROOT / "speedTest.sh"), "2", "64", "64", "64"], capture_output=True, text=True, env=env,
+                       cwd=str(ROOT), timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "Performance:" in r.stdout and "t0:" in r.stdout
+    assert float(re.search(r"Max error:\s*([0-9.eE+-]+)", r.stdout).group(1)) < 1e-11
 
 
 WORKER = r'''

@@ -262,11 +262,13 @@ class StubPlan:
     def kernel_times(self): raise api.DfftError(-1, "stub", "interleaved")
     def destroy(self): pass
 class StubComm:
+    def __init__(self, P, r): self.P, self.r = P, r
+    def info(self): return {"kind": "rccl", "size": self.P, "rank": self.r, "device": 0}
     def destroy(self): pass
 api._BENCH_STUB = True
 api.Plan = StubPlan
 api.Comm.rccl_unique_id = staticmethod(lambda: bytes(range(128)))
-api.Comm.rccl = staticmethod(lambda uid, P, r: StubComm())
+api.Comm.rccl = staticmethod(lambda uid, P, r: StubComm(P, r))
 sys.argv = ["bench.py", "--gpus", os.environ["WORLD_SIZE"], "--size", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
 runpy.run_path(os.path.join(os.environ["DFFT_ROOT"], "bench.py"), run_name="__main__")
 '''

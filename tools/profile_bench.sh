@@ -1,10 +1,14 @@
 #!/bin/bash
-# Round-1 profiling recipe (run on the GPU box through gpurun).  Kernel trace + stats and the HBM PMC counters are
-# collected in SEPARATE passes (gpurun refuses --pmc combined with runtime traces; FETCH_SIZE and WRITE_SIZE do not fit in
-# one pass anyway: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Profiling recipe of the graded bench line (run on the GPU box through gpurun):  tools/profile_bench.sh [round, default r02]
+# Kernel trace + stats and the HBM PMC counters are collected in SEPARATE passes (gpurun refuses --pmc combined with runtime
+# traces; FETCH_SIZE and WRITE_SIZE do not fit in one pass anyway: MI355X_MICROARCH.md "rocprofv3 PMC slots").  The raw
+# output stays under gpurun_out/prof_<round>/ (scratch); tools/summarize_profile.py condenses it into profiles/<round>/ and
+# profiles/hbm_traffic.json, stamped with the sha256 of the library that was profiled.
+ROUND=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
-OUT=$R/gpurun_out/prof_r01; mkdir -p $OUT
+OUT=$R/gpurun_out/prof_$ROUND; mkdir -p $OUT
+sha256sum $R/distributedfft_amd/lib/libdfft_mi355x_pt.so | cut -d' ' -f1 > $OUT/library_sha256.txt
 BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- $BENCH > $OUT/trace_default.log 2>&1
 DFFT_CHUNK_MB=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nochunk -- $BENCH > $OUT/trace_nochunk.log 2>&1
@@ -13,7 +17,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_default -- $BENCH2 > $OUT/pmc_write_default.log 2>&1
 DFFT_CHUNK_MB=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_nochunk -- $BENCH2 > $OUT/pmc_fetch_nochunk.log 2>&1
 DFFT_CHUNK_MB=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_nochunk -- $BENCH2 > $OUT/pmc_write_nochunk.log 2>&1
-find $OUT -name "*.csv" | head -40
 # keep only what is small enough to travel back
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
+find $OUT -name "*.db" -delete
 du -sh $OUT
+cd $R && python tools/summarize_profile.py gpurun_out/prof_$ROUND $ROUND

@@ -1,9 +1,11 @@
-"""Condense the rocprofv3 output of tools/profile_r01.sh (gpurun_out/prof_r01/) into the small files kept under profiles/:
-  profiles/r01/bench_512_fp64_P1_kernel_stats.csv          rocprofv3 --stats rows of the default bench run (library kernels
-                                                           with short names first, the rest as they are)
-  profiles/r01/bench_512_fp64_P1_nochunk_kernel_stats.csv  same with DFFT_CHUNK_MB=0 (whole-slab Z / Y launches)
-  profiles/r01/bench_512_fp64_P1_pmc_summary.csv           FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
-  profiles/hbm_traffic.json                                HBM bytes per X-pass launch for bench.py's roofline.traffic
+"""Condense the rocprofv3 output of tools/profile_bench.sh (gpurun_out/prof_<round>/) into the small files kept under profiles/:
+  profiles/<round>/bench_512_fp64_P1_kernel_stats.csv          rocprofv3 --stats rows of the default bench run (library kernels
+                                                               with short names first, the rest as they are)
+  profiles/<round>/bench_512_fp64_P1_nochunk_kernel_stats.csv  same with DFFT_CHUNK_MB=0 (whole-slab Z / Y launches)
+  profiles/<round>/bench_512_fp64_P1_pmc_summary.csv           FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
+  profiles/hbm_traffic.json                                    fabric bytes per X-pass launch and per t0 stage for bench.py's
+                                                               roofline.traffic, with the sha256 of the profiled library
+usage: python tools/summarize_profile.py [raw dir, default gpurun_out/prof_r02] [round, default r02]
 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports half of the bytes of a wide coalesced streaming
 read -- 128-byte requests tallied at 64 B); both counters are reported in KB and converted with x1024.  They sit on the L2's
 fabric side, so Infinity-Cache hits are included."""
@@ -16,8 +18,11 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-SRC = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / "prof_r01"
-DST = ROOT / "profiles" / "r01"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+SRC = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / f"prof_{ROUND}"
+if not SRC.is_absolute():
+    SRC = ROOT / SRC
+DST = ROOT / "profiles" / ROUND
 
 
 def short(name: str) -> str:
@@ -75,15 +80,40 @@ def pmc():
     xk = [k for k in per if "TuneTransposedStore" in k[1] and "N=512" in k[1] and "dir=1" in k[1]]
     fetch = max([per[k] for k in xk if k[0] == "pmc_fetch_default"], default=None)
     write = max([per[k] for k in xk if k[0] == "pmc_write_default"], default=None)
+    # t0 of one execute = every chunk launch of the Z-row and the Y-column kernel: dispatches per execute x mean per dispatch
+    def t0_total(run):
+        tot, nexec = 0.0, None
+        xn = max([r[-2] for r in out if r[0] == run and "TuneTransposedStore" in r[1]], default=0)  # X launches = executes
+        for r in out:
+            if r[0] != run or "N=512" not in r[1] or "dir=1" not in r[1] or "TuneTransposedStore" in r[1]:
+                continue
+            if xn:
+                tot += r[-1] * r[-2] / xn
+        return tot if xn else None
     if fetch and write:
         traffic = (2 * fetch + write) * 1024
-        j = {"512x512x512_fp64_P1": {
-            "source": "profiles/r01/bench_512_fp64_P1_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                      "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; KB -> bytes x1024)",
-            "fft_cols X(+transpose)": {"FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
-                                        "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 2 * 16 * 512 ** 3}}}
-        (ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps(j, indent=1) + "\n")
+        sha = None
+        try:
+            sha = (SRC / "library_sha256.txt").read_text().strip()
+        except Exception:
+            pass
+        src = (f"profiles/{ROUND}/bench_512_fp64_P1_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+               "FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section; KB -> bytes x1024; fabric-side counters, Infinity-Cache "
+               "hits included)")
+        ent = {"source": src, "library_sha256": sha,
+               "fft_cols X(+transpose)": {"FETCH_SIZE_KB": round(fetch, 1), "WRITE_SIZE_KB": round(write, 1),
+                                          "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": 2 * 16 * 512 ** 3}}
+        f0, w0 = t0_total("pmc_fetch_default"), t0_total("pmc_write_default")
+        if f0 and w0:
+            ent["t0 chunk kernels (Z rows + Y columns)"] = {
+                "FETCH_SIZE_KB": round(f0, 1), "WRITE_SIZE_KB": round(w0, 1), "hbm_bytes_per_launch": (2 * f0 + w0) * 1024,
+                "algorithmic_bytes_per_launch": 2 * 16 * 512 ** 3,
+                "note": "sum over all chunk launches of one execute; the Z -> Y intermediate crosses the fabric twice (written to "
+                        "and read back from the Infinity Cache), hence ~2x the algorithmic bytes of the stage"}
+        (ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps({"512x512x512_fp64_P1": ent}, indent=1) + "\n")
         print("X pass: traffic", traffic, "= %.4f x algorithmic" % (traffic / (2 * 16 * 512 ** 3)))
+        if f0 and w0:
+            print("t0    : traffic", (2 * f0 + w0) * 1024, "= %.4f x algorithmic" % ((2 * f0 + w0) * 1024 / (2 * 16 * 512 ** 3)))
 
 
 if __name__ == "__main__":
