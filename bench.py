@@ -214,8 +214,7 @@ def main():
             # --gpus N means N distinct GPUs: ranks sharing a device would time something else under the same name.
             # (DFFT_BENCH_ALLOW_SHARED_GPU=1: the single-GPU functional tests of this flow, IPC back-ends only.)
             prop = torch.cuda.get_device_properties(dev)
-            ident = str(getattr(prop, "uuid", "")) or f"{getattr(prop, 'pci_bus_id', '?')}:{getattr(prop, 'pci_device_id', '?')}"
-            mine = f"{os.uname().nodename}/{ident}/ordinal{torch.cuda.current_device()}"
+            mine = f"{os.uname().nodename}/{api.device_pci_bus_id(torch.cuda.current_device())}"  # PCI address, not the ordinal
             idents = [None] * world
             dist.all_gather_object(idents, mine)
             note(f"device {torch.cuda.current_device()} of {torch.cuda.device_count()} visible: {prop.name} [{mine}]")

@@ -31,6 +31,7 @@ SIGNATURES = {
     "dfft_version": (C.c_char_p, []),
     "dfft_last_error": (C.c_char_p, []),
     "dfft_device_count": (C.c_int, []),
+    "dfft_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "dfft_length_supported": (C.c_int, [_LL]),
     "dfft_proper_device_count": (C.c_int, [_LLP, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dfft_local_count": (_LL, [_LLP, C.c_int, C.c_int]),

@@ -88,6 +88,13 @@ def fft_mpi_init(N, ini_devices_in_rank: int, mpi_size: int = 1, mpi_rank: int =
 
 
 # ---- communicators -----------------------------------------------------------------------------------------------------
+def device_pci_bus_id(device: int = -1) -> str:
+    """PCI address of a HIP device (-1: the current one) -- dfft_device_pci_bus_id."""
+    buf = C.create_string_buffer(64)
+    L.check(L.load().dfft_device_pci_bus_id(device, buf, 64), "dfft_device_pci_bus_id")
+    return buf.value.decode()
+
+
 class Comm:
     def __init__(self, handle, kind: str, size: int):
         self.handle, self.kind, self.size = handle, kind, size

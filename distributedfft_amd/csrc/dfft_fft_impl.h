@@ -450,9 +450,25 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     };
 
     const unsigned tstep = gridDim.x * G;
+    // XCD-aware tile order for tiles narrower than a cache line (long FFTs whose full-line tile does not fit the LDS): the Q
+    // tiles that share the 128-byte lines of one row segment are given to workgroups Q consecutive "slots" apart on the SAME
+    // XCD (workgroup b runs on XCD b % 8; an observed placement, used for speed only -- any placement gives the same result),
+    // so the second half of every line is served by that XCD's L2 instead of being fetched from memory again by another
+    // XCD, and the two half-line stores meet in one L2.  A permutation of [0, full); tiles beyond keep their index.
+    constexpr int Q = (CB > 1 && G == 1 && CB * sizeof(V) < 128) ? (int)(128 / (CB * sizeof(V))) : 1;
+    const unsigned remap_full = (Q > 1 && tiles_per_a % Q == 0) ? (ntiles / (8u * Q)) * (8u * Q) : 0u;
+    auto map_tile = [&](unsigned lin) -> unsigned {
+        if constexpr (Q > 1) {
+            if (lin < remap_full) {
+                const unsigned xcd = lin & 7u, s = lin >> 3;
+                return ((s / Q) * 8u + xcd) * Q + (s % Q);
+            }
+        }
+        return lin;
+    };
     // loads the E points of the tile group starting at t into dst (zeros for tiles / columns past the end)
     auto load_tile = [&](unsigned t, V* dst) {
-        const unsigned tile = t + g;
+        const unsigned tile = map_tile(t + g);
         bool ok = tile < ntiles;
         const unsigned al = tile / tiles_per_a;
         const unsigned b = tile - al * tiles_per_a;
@@ -479,7 +495,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         if (blockIdx.x * G < ntiles) load_tile(blockIdx.x * G, v);
     }
     for (unsigned t0 = blockIdx.x * G; t0 < ntiles; t0 += tstep) {
-        const unsigned tile = t0 + g;
+        const unsigned tile = map_tile(t0 + g);
         bool valid = tile < ntiles;
         const unsigned al = tile / tiles_per_a;
         const unsigned b = tile - al * tiles_per_a;

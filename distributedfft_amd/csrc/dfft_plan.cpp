@@ -584,6 +584,13 @@ int dfft_device_count(void) {
     return n;
 }
 
+int dfft_device_pci_bus_id(int device, char* buf, int len) {
+    if (!buf || len < 16) return fail(DFFT_EINVAL, "dfft_device_pci_bus_id: buffer too small");
+    if (device < 0) DFFT_HIP_TRY(hipGetDevice(&device));
+    DFFT_HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return DFFT_OK;
+}
+
 int dfft_length_supported(long long n) { return (n > 0 && n < (1ll << 30) && fft_length_supported((int)n)) ? 1 : 0; }
 
 int dfft_proper_device_count(const long long N[3], int ini_devices_in_rank, int nranks, int rank, int real_devices,

@@ -71,6 +71,10 @@ const char* dfft_version(void);
 const char* dfft_last_error(void);
 /* Number of visible HIP devices (0 if none).  hipGetDeviceCount in fftSpeed3d_c2c.cpp:33-34. */
 int dfft_device_count(void);
+/* PCI address ("domain:bus:device.function", hipDeviceGetPCIBusId) of HIP device `device` (-1: the calling thread's current
+ * device): the identity a multi-process launch compares to prove that its ranks sit on distinct GPUs -- ordinals do not
+ * (HIP_VISIBLE_DEVICES renumbers them per process).  Returns 0 and a NUL-terminated string in buf[0..len). */
+int dfft_device_pci_bus_id(int device, char* buf, int len);
 /* 1 if FFT length n is supported: any product of 2, 3, 5, 7 up to 4096 (tuned plans for the lengths listed in
  * csrc/dfft_plans.h, a run-time-scheduled kernel for the rest) -- the single-pass range of the reference's generator. */
 int dfft_length_supported(long long n);
