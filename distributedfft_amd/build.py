@@ -114,6 +114,13 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     if force or _newer(s3d, [s3d_src, lib] + hdrs):
         _run([HIPCC] + COMMON + ["-x", "hip", str(s3d_src), "-x", "none", "-o", str(s3d), "-L" + str(LIBDIR),
                                  "-ldfft_mi355x", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
+    # Test_1D / Test_2D: the reference's batched component benchmarks (templateFFT/batchTest) on the C-ABI
+    bt_src = CSRC / "batch_test.cpp"
+    for dim in (1, 2):
+        exe = LIBDIR / f"Test_{dim}D"
+        if force or _newer(exe, [bt_src, lib] + hdrs):
+            _run([HIPCC] + COMMON + ["-x", "hip", f"-DBATCH_DIM={dim}", str(bt_src), "-x", "none", "-o", str(exe), "-L" + str(LIBDIR),
+                                     "-ldfft_mi355x", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
     return lib
 
 

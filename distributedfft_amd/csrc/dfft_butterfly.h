@@ -81,19 +81,26 @@ template <int DIR, class V> struct Butterfly<4, DIR, V> {
 };
 
 template <int DIR, class V> struct Butterfly<5, DIR, V> {
+    // Real parts in the Winograd form  m1,2 = (u0 - (t1 + t2)/4) +- (sqrt(5)/4)(t1 - t2)  [cos(2pi/5) = (sqrt5 - 1)/4,
+    // cos(4pi/5) = -(sqrt5 + 1)/4]: a constant offset common to all five inputs cancels EXACTLY in (u0 - t5/4) and in
+    // (t1 - t2), instead of surviving as offset * (1 + 2 c1 + 2 c2) = offset * O(eps).  The reference's batch tests
+    // transform a ramp with values up to 2^26 (Test_1D.cpp:49-52); with the plain cosine form their round-trip error
+    // is 1e-8, with this one 1e-13 like the published rows (templateFFT/csv/batch_result1D.csv:2-6).  Two real
+    // multiplications per component instead of four.
     static __device__ __forceinline__ void run(V* u) {
         using Rt = typename real_of<V>::type;
-        const Rt c1 = Rt(0.30901699437494742410229341718282);   // cos(2pi/5)
-        const Rt c2 = Rt(-0.80901699437494742410229341718282);  // cos(4pi/5)
+        const Rt k5 = Rt(0.55901699437494742410229341718282);   // sqrt(5)/4
         const Rt s1 = Rt(0.95105651629515357211643933337938);   // sin(2pi/5)
         const Rt s2 = Rt(0.58778525229247312916870595463907);   // sin(4pi/5)
         V t1 = cadd(u[1], u[4]), t2 = cadd(u[2], u[3]);
         V t3 = csub(u[1], u[4]), t4 = csub(u[2], u[3]);
-        V m1 = V{u[0].x + c1 * t1.x + c2 * t2.x, u[0].y + c1 * t1.y + c2 * t2.y};
-        V m2 = V{u[0].x + c2 * t1.x + c1 * t2.x, u[0].y + c2 * t1.y + c1 * t2.y};
+        V t5 = cadd(t1, t2);
+        V m = V{u[0].x - Rt(0.25) * t5.x, u[0].y - Rt(0.25) * t5.y};
+        V r = cscale(csub(t1, t2), k5);
+        V m1 = cadd(m, r), m2 = csub(m, r);
         V q1 = mul_mi<DIR>(V{s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y});
         V q2 = mul_mi<DIR>(V{s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y});
-        u[0] = V{u[0].x + t1.x + t2.x, u[0].y + t1.y + t2.y};
+        u[0] = cadd(u[0], t5);
         u[1] = cadd(m1, q1);
         u[4] = csub(m1, q1);
         u[2] = cadd(m2, q2);
@@ -112,10 +119,14 @@ template <int DIR, class V> struct Butterfly<7, DIR, V> {
         const V t1 = cadd(u[1], u[6]), t2 = cadd(u[2], u[5]), t3 = cadd(u[3], u[4]);
         const V d1 = csub(u[1], u[6]), d2 = csub(u[2], u[5]), d3 = csub(u[3], u[4]);
         const V a0 = u[0];
-        // m_j = a0 + sum_k cos(2 pi j k / 7) t_k,  n_j = sum_k sin(2 pi j k / 7) d_k   (j k mod 7 folded to 1..3)
-        const V m1 = V{a0.x + c1 * t1.x + c2 * t2.x + c3 * t3.x, a0.y + c1 * t1.y + c2 * t2.y + c3 * t3.y};
-        const V m2 = V{a0.x + c2 * t1.x + c3 * t2.x + c1 * t3.x, a0.y + c2 * t1.y + c3 * t2.y + c1 * t3.y};
-        const V m3 = V{a0.x + c3 * t1.x + c1 * t2.x + c2 * t3.x, a0.y + c3 * t1.y + c1 * t2.y + c2 * t3.y};
+        // m_j = a0 + sum_k cos(2 pi j k / 7) t_k,  n_j = sum_k sin(2 pi j k / 7) d_k   (j k mod 7 folded to 1..3).
+        // c1 + c2 + c3 = -1/2, so m_j = (a0 - t3/2) + c_{j1} (t1 - t3) + c_{j2} (t2 - t3): a constant offset common to all
+        // seven inputs cancels exactly in each bracket (see Butterfly<5>)
+        const V e1 = csub(t1, t3), e2 = csub(t2, t3);
+        const V b0 = V{a0.x - Rt(0.5) * t3.x, a0.y - Rt(0.5) * t3.y};
+        const V m1 = V{b0.x + c1 * e1.x + c2 * e2.x, b0.y + c1 * e1.y + c2 * e2.y};
+        const V m2 = V{b0.x + c2 * e1.x + c3 * e2.x, b0.y + c2 * e1.y + c3 * e2.y};
+        const V m3 = V{b0.x + c3 * e1.x + c1 * e2.x, b0.y + c3 * e1.y + c1 * e2.y};
         const V n1 = mul_mi<DIR>(V{s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y});
         const V n2 = mul_mi<DIR>(V{s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y});
         const V n3 = mul_mi<DIR>(V{s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y});

@@ -313,8 +313,8 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
                                   : ((size_t)LDS_ELEMS * G * sizeof(V) + P::N * sizeof(typename VecTraits<V>::W) <= 128 * 1024
                                          ? TW_LDS : TW_GLOBAL);
     static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;  // in units of W
-    static constexpr size_t TW_BYTES = (size_t)TW_ELEMS * sizeof(typename VecTraits<V>::W);
-    static_assert(TW_BYTES % 16 == 0, "the exchange tile behind the twiddle copy must stay 16-byte aligned");
+    // rounded up so that the exchange tile behind the twiddle copy stays 16-byte aligned (odd lengths in fp32)
+    static constexpr size_t TW_BYTES = ((size_t)TW_ELEMS * sizeof(typename VecTraits<V>::W) + 15) / 16 * 16;
     static constexpr size_t LDS_BYTES = (size_t)LDS_ELEMS * G * sizeof(V) + TW_BYTES;
 };
 

@@ -4,6 +4,8 @@
 // fold 2s into radix 8 then 4, largest radix first, 8 complex registers per thread for powers of two,
 // 12/24 when a factor 3 is present) as a static table; nothing is generated at run time.
 // X(N, group, E, radices...) -- "group" only spreads the instantiations over translation units.
+// Powers of 3 and 5 (the reference's published component rows 243, 625, 2187, 3125: templateFFT/csv/batch_result1D.csv:5,6,14,16;
+// 2D 243^2, 729x243: batch_result2D.csv:32,33) run radix-3 / radix-5 stages with 9 (25 for 3125) points per thread.
 #pragma once
 
 #define DFFT_PLAN_TABLE(X)        \
@@ -46,6 +48,13 @@
     X(640, 8, 20, 5, 4, 4, 4, 2)  \
     X(1000, 8, 10, 5, 5, 5, 2, 2, 2) \
     X(1280, 9, 20, 5, 4, 4, 4, 4) \
-    X(1536, 9, 24, 8, 8, 8, 3)
+    X(1536, 9, 24, 8, 8, 8, 3)    \
+    X(27, 0, 9, 3, 3, 3)          \
+    X(81, 1, 9, 3, 3, 3, 3)       \
+    X(243, 2, 9, 3, 3, 3, 3, 3)   \
+    X(729, 4, 9, 3, 3, 3, 3, 3, 3) \
+    X(2187, 6, 9, 3, 3, 3, 3, 3, 3, 3) \
+    X(625, 5, 5, 5, 5, 5, 5)      \
+    X(3125, 3, 25, 5, 5, 5, 5, 5)
 
 #define DFFT_NUM_INST_GROUPS 10

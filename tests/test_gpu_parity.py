@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 TOL = {"f64": 1e-11, "f32": 5e-4}
 # tuned plans (dfft_plans.h) ...
 TUNED = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 25, 32, 40, 48, 49, 64, 80, 96, 100, 125, 128, 160, 192, 200, 256, 320, 343,
-         384, 400, 512, 640, 768, 1000, 1024, 1280, 1536, 2048]
+         384, 400, 512, 640, 768, 1000, 1024, 1280, 1536, 2048, 27, 81, 243, 625, 729, 2187, 3125]
 # ... and 7-smooth lengths served by the run-time-scheduled kernel (dfft_generic.hip): every radix mix, up to 4096
-GENERIC = [15, 18, 20, 21, 27, 35, 36, 45, 50, 60, 63, 72, 81, 90, 105, 120, 144, 210, 240, 243, 250, 360, 500, 625, 720, 729,
-           800, 2000, 2187, 2401, 3072, 4000, 4096]
+GENERIC = [15, 18, 20, 21, 35, 36, 45, 50, 60, 63, 72, 90, 105, 120, 144, 210, 240, 250, 360, 500, 720,
+           800, 2000, 2401, 3072, 4000, 4096]
 LENGTHS = TUNED + GENERIC
 
 
