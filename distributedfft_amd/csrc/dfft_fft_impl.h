@@ -632,6 +632,7 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     int bpc = blocks_per_cu[dev];
     if (L.blocks_per_cu_limit > 0 && L.blocks_per_cu_limit < bpc) bpc = L.blocks_per_cu_limit;
     long long grid = (long long)device_info().cus * bpc;
+    if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
     if (grid > nblocks_needed) grid = nblocks_needed;
     if (grid < 1) return hipSuccess;
     (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)

@@ -51,6 +51,8 @@ struct FftLaunch {
     double      scale;    // results are multiplied by this before the store (0 or 1 = no scaling)
     int         blocks_per_cu_limit;  // > 0: cap the persistent grid at this many blocks per CU (leaves room for a
                                       // kernel running concurrently on another stream)
+    int         grid_limit;           // > 0: cap the persistent grid at this many workgroups (HBM writes run faster from
+                                      // fewer concurrent writers, profiles/r02/README.md section 1; tuning knob)
 };
 enum {
     FFT_HINT_STREAM_IN = 1,   // input is read once and must not displace the cache-resident chunk: non-temporal loads

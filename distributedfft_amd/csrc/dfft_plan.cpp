@@ -99,6 +99,12 @@ static AxisMap plain_axis(long long n, long long stride, long long cstride) {
     return m;
 }
 
+// experiment knobs: DFFT_Z_GRID / DFFT_Y_GRID / DFFT_X_GRID cap the persistent grid of the respective pass
+static int env_grid(const char* name) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : 0;
+}
+
 static int check_launch(hipError_t e, const char* what) {
     if (e == hipSuccess) return DFFT_OK;
     if (e == hipErrorInvalidValue) return fail(DFFT_EUNSUPPORTED, std::string(what) + ": no gfx950 kernel for this length/precision");
@@ -128,6 +134,8 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
     L.scale = scale;
     L.tiles_per_a = 1;
     L.ncols = 1;
+    static const int zgrid = env_grid("DFFT_Z_GRID");
+    L.grid_limit = zgrid;
     return check_launch(launch_fft(L, s), "fft_rows");
 }
 
@@ -259,6 +267,8 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.a_first = x0;
     L.hints = hints;
     L.ncols = (int)n2;
+    static const int ygrid = env_grid("DFFT_Y_GRID");
+    L.grid_limit = ygrid;
     return check_launch(launch_fft(L, p->stream), "Y pass");
 }
 
@@ -302,6 +312,8 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     L.na = ys;
     L.scale = p->scale;
     L.ncols = (int)n2;
+    static const int xgrid = env_grid("DFFT_X_GRID");
+    L.grid_limit = xgrid;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
 
