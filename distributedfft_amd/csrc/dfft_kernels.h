@@ -60,6 +60,7 @@ enum {
 };
 
 bool fft_length_supported(int n);
+bool fft_length_tuned(int n);  // served by a static plan of dfft_plans.h (not by the run-time-scheduled kernel)
 // run-time-scheduled kernel for 7-smooth lengths <= 4096 that have no tuned plan (dfft_generic.hip)
 bool       generic_length_supported(int n);
 hipError_t launch_generic(const struct FftLaunch& L, hipStream_t stream);

@@ -26,6 +26,16 @@ bool fft_length_supported(int n) {
     }
 }
 
+bool fft_length_tuned(int n) {
+    switch (n) {
+#define DFFT_CASE(N, GRP, E, ...) case N:
+        DFFT_PLAN_TABLE(DFFT_CASE)
+#undef DFFT_CASE
+        return true;
+        default: return false;
+    }
+}
+
 hipError_t launch_fft(const FftLaunch& L, hipStream_t stream) {
     if ((L.cols ? L.na : L.ntiles) <= 0) return hipSuccess;
     switch (L.n) {

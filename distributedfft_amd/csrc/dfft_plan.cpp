@@ -111,9 +111,16 @@ static int check_launch(hipError_t e, const char* what) {
     return fail(DFFT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// contiguous rows: `rows` FFTs of length n, row pitch n
+// Where the rows of an [x][y][z] slab sit: elements between consecutive rows and between consecutive planes.  The natural
+// layout is {N2, N1*N2}; the plan's padded work buffer (dfft_plan_s::wbuf) uses {N2 + one line, N1*pitch + one line}.
+struct SlabLayout {
+    long long pitch, plane;
+};
+
+// contiguous rows: `rows` FFTs of length n; row pitch n, or (lin/lout given) rows_per_plane rows per plane in the given layouts
 static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s,
-                    long long first_row = 0, int hints = 0, double scale = 1.0) {
+                    long long first_row = 0, int hints = 0, double scale = 1.0, const SlabLayout* lin = nullptr,
+                    const SlabLayout* lout = nullptr, long long rows_per_plane = 0) {
     const void* tw = nullptr;
     int         rc = get_twiddles(n, dtype, &tw);
     if (rc) return rc;
@@ -134,6 +141,13 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
     L.scale = scale;
     L.tiles_per_a = 1;
     L.ncols = 1;
+    if (lin && lout && rows_per_plane > 0) {  // tile = (plane a, row b): base = a * plane + b * pitch (CB = 1 for rows)
+        if (first_row % rows_per_plane != 0 || rows_per_plane >= (1ll << 31)) return fail(DFFT_EINVAL, "fft_rows: chunk is not whole planes");
+        L.itile = TileMap{lin->plane, lin->pitch};
+        L.otile = TileMap{lout->plane, lout->pitch};
+        L.tiles_per_a = (int)rows_per_plane;
+        L.a_first = first_row / rows_per_plane;
+    }
     static const int zgrid = env_grid("DFFT_Z_GRID");
     L.grid_limit = zgrid;
     return check_launch(launch_fft(L, s), "fft_rows");
@@ -176,6 +190,13 @@ struct dfft_plan_s {
     // X-plane part is exchanged sub-block by sub-block and the X pass of sub-block k runs while sub-block k+1 is in flight
     int                     ycuts = 1;
     std::vector<hipEvent_t> y_ev;
+    // Padded work buffer for the Z <-> Y (and, on a single GPU, Y <-> X) intermediate of the fused pipeline: rows one
+    // cache line longer than N2 and planes one more line apart, so that the column kernels' 128-byte segments -- N1 of
+    // them one row pitch apart (Y pass), N0 of them one plane apart (X pass) -- do not all fall on the same memory
+    // channels.  With power-of-two extents the natural strides (8 KiB, 4 MiB at 512^3 fp64) cost 11-15 % of the passes'
+    // data rate (tools/membench4.hip, profiles/r02/README.md section 1).  Caller-visible buffers keep the reference layouts.
+    void*                   wbuf = nullptr;
+    SlabLayout              wl{0, 0};
 };
 
 static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
@@ -218,8 +239,9 @@ static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
 }
 
 // Y pass.  Natural side: [xs][N1][N2].  Packed side: [d][xs][yl_d][N2].
+// lay_in / lay_out: layout of the natural side(s) (nullptr = {N2, N1*N2}); ignored for a packed side.
 static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_is_out, bool use_packed, long long x0,
-                    long long nx, int hints = 0) {
+                    long long nx, int hints = 0, const SlabLayout* lay_in = nullptr, const SlabLayout* lay_out = nullptr) {
     const int       n1 = (int)p->N[1];
     const long long n2 = p->N[2];
     const void*     tw = nullptr;
@@ -234,8 +256,8 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.in = in;
     L.out = out;
     L.tw = tw;
-    AxisMap natural = plain_axis(n1, n2, 1);
-    TileMap nat_tile{(long long)n1 * n2, 1};
+    const SlabLayout nat{n2, (long long)n1 * n2};
+    const SlabLayout li = lay_in ? *lay_in : nat, lo = lay_out ? *lay_out : nat;
     // packed side: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even X and Y splits only) [k][d][xs][yl/ycuts][N2]:
     // sub-block k of the send buffer is exactly the region the X pass of sub-block k overwrites with its result, so a
     // result never lands on send data that is still in flight (execute_forward)
@@ -250,10 +272,10 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     packed.cstride = 1;
     packed.last_delta = p->ycuts > 1 ? 0 : (p->sy.size(p->P - 1) - p->sy.blk) * n2;
     TileMap pk_tile{ysub * n2, 1};
-    L.imap = natural;
-    L.itile = nat_tile;
-    L.omap = natural;
-    L.otile = nat_tile;
+    L.imap = plain_axis(n1, li.pitch, 1);
+    L.itile = TileMap{li.plane, 1};
+    L.omap = plain_axis(n1, lo.pitch, 1);
+    L.otile = TileMap{lo.plane, 1};
     if (use_packed) {
         if (packed_side_is_out) {
             L.omap = packed;
@@ -275,7 +297,9 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
 // X pass.  Slab side: [N0][ys][N2] (x slowest).  Transposed side: [ys][N2][N0] (kx fastest).
 // keep_slab: store [x][ys][N2] again instead of the transposed [ys][N2][kx] (natural-order plans)
 // ys_part > 0: only a [N0][ys_part][N2] sub-slab (in/out already point at it)
-static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = false, long long ys_part = 0) {
+// slab_lay: layout of the slab side when it is the plan's padded work buffer (single GPU: ys == N1), else [x][ys][N2]
+static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = false, long long ys_part = 0,
+                    const SlabLayout* slab_lay = nullptr) {
     const int       n0 = (int)p->N[0];
     const long long n2 = p->N[2];
     const long long ys = ys_part > 0 ? ys_part : p->ys;
@@ -291,8 +315,8 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     L.in = in;
     L.out = out;
     L.tw = tw;
-    AxisMap slab = plain_axis(n0, ys * n2, 1);
-    TileMap slab_tile{n2, 1};
+    AxisMap slab = plain_axis(n0, slab_lay ? slab_lay->plane : ys * n2, 1);
+    TileMap slab_tile{slab_lay ? slab_lay->pitch : n2, 1};
     AxisMap tr = plain_axis(n0, 1, n0);
     TileMap tr_tile{n2 * (long long)n0, (long long)n0};
     if (keep_slab) {
@@ -363,6 +387,11 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const bool      y_packs = fused && p->exch;
+    // where the Z pass puts its rows for the Y pass: the padded work buffer when the plan has one (fused pipelines)
+    const SlabLayout nat{n2, n1 * n2};
+    void*            zdst = (fused && p->wbuf) ? p->wbuf : p->buf1;
+    const SlabLayout zl = (fused && p->wbuf) ? p->wl : nat;
+    const SlabLayout *lz = (fused && p->wbuf) ? &zl : nullptr, *lnat = lz ? &nat : nullptr;  // row launches: layouts only when padded
     if (y_packs && (p->flags & DFFT_PLAN_OVERLAP) && p->part_planes > 0) {
         // ---- t0 pipelined against t2: the exchange of plane part k (stream2) runs while the Z+Y passes of part k+1
         // (stream) compute.  Any X-plane sub-range of the packed send layout is contiguous on both sides, so the parts
@@ -374,9 +403,9 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
             long long x0, nx;
             part_range(p->xs, p->part_planes, k, &x0, &nx);
             if (nx > 0) {
-                DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
-                                  zsrc != p->buf1 ? FFT_HINT_STREAM_IN : 0));
-                DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT));
+                DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
+                                  zsrc != zdst ? FFT_HINT_STREAM_IN : 0, 1.0, lnat, lz, lz ? n1 : 0));
+                DFFT_TRY(launch_y(p, zdst, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT, &zl));
             }
             hipStream_t xs_ = rccl ? p->stream2 : p->stream;  // LOCAL: host-synchronising, same call sequence
             if (rccl) {
@@ -420,11 +449,11 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
     for (long long x0 = 0; x0 < p->xs; x0 += cp) {
         const long long nx = std::min(cp, p->xs - x0);
-        DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
-                          (chunked && zsrc != p->buf1) ? FFT_HINT_STREAM_IN : 0));
+        DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
+                          (chunked && zsrc != zdst) ? FFT_HINT_STREAM_IN : 0, 1.0, lnat, lz, lz ? n1 : 0));
         if (!sync && p->timed && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
-        if (y_packs) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, chunked ? FFT_HINT_STREAM_OUT : 0));  // Y FFT + pack in one pass
-        else DFFT_TRY(launch_y(p, p->buf1, p->buf1, true, false, x0, nx));
+        if (y_packs) DFFT_TRY(launch_y(p, zdst, p->buf2, true, true, x0, nx, chunked ? FFT_HINT_STREAM_OUT : 0, &zl));  // Y FFT + pack in one pass
+        else DFFT_TRY(launch_y(p, zdst, zdst, true, false, x0, nx, 0, &zl, &zl));
     }
     if (y_packs) {
         DFFT_TRY(clk.end_stage());
@@ -440,7 +469,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         DFFT_TRY(clk.end_stage());
     }
     // ---- t2: exchange ----
-    const void* xsrc = p->buf1;
+    const void* xsrc = p->exch ? p->buf1 : zdst;  // single GPU: the X pass reads what the Y pass left (possibly padded)
     if (p->exch) {
         DFFT_TRY(comm_exchange(p->comm, p->xd, p->stream));
     } else if (!fused) {
@@ -451,7 +480,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     DFFT_TRY(clk.end_stage());
     // ---- t3: X FFT (+ transpose to [yl][N2][N0]) ----
     if (fused) {
-        DFFT_TRY(launch_x(p, xsrc, p->buf2));
+        DFFT_TRY(launch_x(p, xsrc, p->buf2, false, 0, (!p->exch && p->wbuf) ? &zl : nullptr));
     } else {
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, n0, p->ys * n2, p->stream);
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
@@ -499,6 +528,11 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     StageClock      clk{p, sync};
     DFFT_TRY(clk.begin());
     const void* src = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
+    // where the inverse Y pass leaves its columns for the inverse Z pass: the padded work buffer when the plan has one
+    const SlabLayout nat{n2, n1 * n2};
+    void*            ydst = (fused && p->wbuf) ? p->wbuf : p->buf2;
+    const SlabLayout yl = (fused && p->wbuf) ? p->wl : nat;
+    const SlabLayout *ly = (fused && p->wbuf) ? &yl : nullptr, *lnat = ly ? &nat : nullptr;
     if (fused && p->exch && (p->flags & DFFT_PLAN_OVERLAP) && p->part_planes > 0) {
         // ---- mirror image of the overlapped forward pipeline: the inverse X pass runs Y sub-block by sub-block into the
         // send buffer [k][x all][y in k][N2] and sub-block k is exchanged (stream2) while sub-block k+1 is transformed;
@@ -536,16 +570,18 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
             long long x0, nx;
             part_range(p->xs, p->part_planes, i, &x0, &nx);
             if (nx > 0) {
-                DFFT_TRY(launch_y(p, p->buf1, p->buf2, false, true, x0, nx, FFT_HINT_STREAM_IN));
-                DFFT_TRY(fft_rows(p->buf2, p->buf2, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1));
+                DFFT_TRY(launch_y(p, p->buf1, ydst, false, true, x0, nx, FFT_HINT_STREAM_IN, nullptr, &yl));
+                DFFT_TRY(fft_rows(ydst, p->buf2, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1, 0, 1.0, ly, lnat, ly ? n1 : 0));
             }
         }
         DFFT_TRY(clk.end_stage());
         return DFFT_OK;
     }
     // ---- inverse X FFT: [ys][N2][kx] -> [x][ys][N2] ----
+    // (single GPU: straight into the padded work buffer -- the plane-strided 128-byte stores are the scattered side here)
+    const bool xw = fused && !p->exch && p->wbuf;
     if (fused) {
-        DFFT_TRY(launch_x(p, src, p->buf2));
+        DFFT_TRY(launch_x(p, src, xw ? p->wbuf : p->buf2, false, 0, xw ? &yl : nullptr));
     } else {
         DFFT_TRY(fft_rows(src, p->buf1, (int)n0, p->ys * n2, p->dtype, p->direction, p->stream, 0, 0, p->scale));
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, p->ys * n2, n0, p->stream);
@@ -576,10 +612,12 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
     for (long long x0 = 0; x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
-        if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0));
+        if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
+        else if (xw) DFFT_TRY(launch_y(p, p->wbuf, p->wbuf, false, false, x0, nx, 0, &yl, &yl));
         else DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false, x0, nx));
         if (!sync && p->timed && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
-        DFFT_TRY(fft_rows(ybuf, ybuf, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1));
+        if (fused && p->wbuf) DFFT_TRY(fft_rows(ydst, ybuf, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1, 0, 1.0, ly, lnat, n1));
+        else DFFT_TRY(fft_rows(ybuf, ybuf, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1));
     }
     DFFT_TRY(clk.end_stage());
     return DFFT_OK;
@@ -806,15 +844,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         delete p;
         return fail(DFFT_EINVAL, "dfft_plan_create: DFFT_PLAN_NATURAL is a fused-pipeline option");
     }
-    {
-        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md); DFFT_CHUNK_MB=0 disables, =k overrides
-        long long   mb = 256;
-        const char* e = getenv("DFFT_CHUNK_MB");
-        if (e) mb = atoll(e);
-        const long long plane_bytes = n1 * n2 * (long long)elem_bytes(dtype);
-        p->chunk_planes = mb > 0 ? std::max(1ll, (mb << 20) / plane_bytes) : 0;
-        if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
-    }
+    p->chunk_planes = 0;  // decided below, once the layout of the Z -> Y intermediate is known
     p->buf1 = nullptr;
     p->stream = nullptr;
     for (auto& e : p->ev) e = nullptr;
@@ -914,6 +944,45 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             dfft_plan_destroy(p);
             return rc;
         }
+    }
+    // padded work buffer (dfft_plan_s::wbuf): fused, non-natural pipelines whose rows are whole cache lines and whose three
+    // lengths run on the tuned kernels (the run-time-scheduled kernel keeps plain rows).  DFFT_PAD=0 switches it off.
+    {
+        const char* pe = getenv("DFFT_PAD");
+        const long long line = 128 / (long long)elem_bytes(dtype);
+        if (!(pe && *pe == '0') && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && (n2 % line) == 0 &&
+            fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2)) {
+            // lines of padding per row / per plane (tuning knobs DFFT_PAD_ROW, DFFT_PAD_PLANE; measured: profiles/r02)
+            const char* pr = getenv("DFFT_PAD_ROW");
+            const char* pp = getenv("DFFT_PAD_PLANE");
+            const long long row_lines = pr ? atoll(pr) : 0, plane_lines = pp ? atoll(pp) : 3;
+            p->wl.pitch = n2 + row_lines * line;
+            p->wl.plane = n1 * p->wl.pitch + plane_lines * line;
+            if (p->xs * p->wl.plane < (1ll << 31)) {
+                e = hipMalloc(&p->wbuf, (size_t)p->xs * p->wl.plane * elem_bytes(dtype));
+                if (e != hipSuccess) {
+                    dfft_plan_destroy(p);
+                    return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+                }
+            }
+        }
+    }
+    {
+        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of planes of the
+        // intermediate (padded planes when the work buffer is in use) that fits, then evened out over the chunks.
+        // DFFT_CHUNK_MB=0 disables, =k overrides the capacity.
+        long long   mb = 256;
+        const char* ce = getenv("DFFT_CHUNK_MB");
+        if (ce) mb = atoll(ce);
+        const long long plane_bytes = (p->wbuf ? p->wl.plane : n1 * n2) * (long long)elem_bytes(dtype);
+        if (mb > 0) {
+            // (with padded 4 MiB planes 63 fit, i.e. 9 chunks of 57: t0 1.40 ms instead of 1.37 with 8 x 64 planes that spill
+            // the cache by a few KiB, but the X pass then still finds the last chunk in the cache: 0.72 vs 0.77 ms)
+            const long long fit = std::max(1ll, (mb << 20) / plane_bytes);
+            const long long nchunks = (p->xs + fit - 1) / fit;
+            p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
+        }
+        if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
     // warm the twiddle caches so execute never allocates
     for (long long n : {n0, n1, n2}) {
@@ -1034,6 +1103,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
+    if (plan->wbuf) hipFree(plan->wbuf);
     delete plan;
     return DFFT_OK;
 }

@@ -62,7 +62,7 @@ def test_fullsize_properties(gpu, N, P, prec, overlap):
     free, _ = torch.cuda.mem_get_info()
     S = 16 if prec == "f64" else 8
     slabs = [api.get_max_data_count(n0, n1, n2, P, g == P - 1) * S for g in range(P)]
-    need = 4 * sum(slabs) + 6 * max(slabs) + (1 << 30)
+    need = 5 * sum(slabs) + 6 * max(slabs) + (1 << 30)  # + the plan's padded work buffer
     if need > free:
         pytest.skip(f"needs {need / 2**30:.0f} GiB of HBM, {free / 2**30:.0f} free")
 

@@ -24,8 +24,8 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-enum { SEG128_8K = 0, SEG128_4M = 1, SEG128_1K = 2, SEG1K_512K = 3, RUN64K = 4 };
-static const char* kNames[] = {"seg128@8K", "seg128@4M", "seg128@1K", "seg1K@512K", "run64K"};
+enum { SEG128_8K = 0, SEG128_4M = 1, SEG128_1K = 2, SEG1K_512K = 3, RUN64K = 4, SEG128_4M_PAD128 = 5, SEG128_4M_PAD1K = 6, SEG128_4M_PAD4K = 7, SEG128_4M_PAD64K = 8, SEG128_8K_PAD = 9, SEG128_ROWPAD_4M = 10, SEG128_ROWPAD_4M_PAD = 11, SEG128_4M_PAD384 = 12, SEG128_4M_PAD640 = 13 };
+static const char* kNames[] = {"seg128@8K", "seg128@4M", "seg128@1K", "seg1K@512K", "run64K", "seg128@4M+128", "seg128@4M+1K", "seg128@4M+4K", "seg128@4M+64K", "seg128@8K+128", "rowpad@4M+64K", "rowpad@4M+64K+128", "seg128@4M+384", "seg128@4M+640"};
 
 // element offset of point k (0..7) of thread tid in tile t, for a 512^3 volume of 16-byte elements
 template <int PAT> __device__ __forceinline__ size_t addr(unsigned t, int tid, int k) {
@@ -37,6 +37,16 @@ template <int PAT> __device__ __forceinline__ size_t addr(unsigned t, int tid, i
     } else if (PAT == SEG128_4M) {             // tile = (y, b): [idx][y][b*8 + c]
         const unsigned y = t >> 6, b = t & 63;
         return ((size_t)idx * 512 + y) * 512 + b * 8 + c;
+    } else if (PAT == SEG128_8K_PAD) {         // Y pass on rows padded by one line: [x][idx][520]
+        const unsigned x = t >> 6, b = t & 63;
+        return ((size_t)x * 512 + idx) * 520 + b * 8 + c;
+    } else if (PAT == SEG128_ROWPAD_4M || PAT == SEG128_ROWPAD_4M_PAD) {  // X pass on that layout (+ one line per plane)
+        const unsigned y = t >> 6, b = t & 63;
+        return (size_t)idx * (512 * 520 + (PAT == SEG128_ROWPAD_4M_PAD ? 8 : 0)) + (size_t)y * 520 + b * 8 + c;
+    } else if (PAT >= SEG128_4M_PAD128) {      // as seg128@4M with the plane stride padded (not a power of two)
+        const unsigned y = t >> 6, b = t & 63;
+        const size_t pad = PAT == SEG128_4M_PAD128 ? 8 : (PAT == SEG128_4M_PAD1K ? 64 : (PAT == SEG128_4M_PAD4K ? 256 : (PAT == SEG128_4M_PAD384 ? 24 : (PAT == SEG128_4M_PAD640 ? 40 : 4096))));
+        return (size_t)idx * (512 * 512 + pad) + (size_t)y * 512 + b * 8 + c;
     } else if (PAT == SEG128_1K) {             // tile = (g, b, r): [g][b][idx][r][c], G = 8
         const unsigned r = t & 7, gb = t >> 3;
         return (((size_t)gb * 512 + idx) * 8 + r) * 8 + c;
@@ -108,8 +118,8 @@ template <int RP, int WP> void run() {
 
 int main() {
     const size_t n = 512ull * 512 * 512;
-    CK(hipMalloc(&g_a, n * 16));
-    CK(hipMalloc(&g_b, n * 16));
+    CK(hipMalloc(&g_a, n * 16 + 512ull * 8192 * 16));
+    CK(hipMalloc(&g_b, n * 16 + 512ull * 8192 * 16));
     CK(hipMemset(g_a, 1, n * 16));
     CK(hipMemset(g_b, 0, n * 16));
     CK(hipStreamCreateWithFlags(&g_s, hipStreamNonBlocking));
@@ -120,6 +130,16 @@ int main() {
     run<SEG128_8K, RUN64K>();
     run<SEG128_8K, SEG1K_512K>();
     run<SEG128_4M, RUN64K>();
+    run<SEG128_4M_PAD128, RUN64K>();
+    run<SEG128_4M_PAD1K, RUN64K>();
+    run<SEG128_4M_PAD4K, RUN64K>();
+    run<SEG128_4M_PAD64K, RUN64K>();
     run<SEG128_1K, RUN64K>();
+    run<SEG128_4M_PAD384, RUN64K>();
+    run<SEG128_4M_PAD640, RUN64K>();
+    run<SEG128_8K_PAD, SEG128_8K_PAD>();
+    run<RUN64K, SEG128_8K_PAD>();
+    run<SEG128_ROWPAD_4M, RUN64K>();
+    run<SEG128_ROWPAD_4M_PAD, RUN64K>();
     return 0;
 }
