@@ -950,7 +950,12 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     {
         const char* pe = getenv("DFFT_PAD");
         const long long line = 128 / (long long)elem_bytes(dtype);
-        if (!(pe && *pe == '0') && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && (n2 % line) == 0 &&
+        // Only where it pays (profiles/r02/experiments/padding_sweep.log): planes a multiple of 1 MiB apart -- other strides
+        // spread over the channels by themselves (384^3: no gain) -- and slabs larger than the 256 MiB Infinity Cache
+        // (cache-resident problems do not reach HBM's channels: 256^3 is 6 % slower with the extra buffer).
+        const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
+        const bool      pays = (pe && *pe == '1') || (plane_b % (1ll << 20) == 0 && p->xs * plane_b > (256ll << 20));
+        if (!(pe && *pe == '0') && pays && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && (n2 % line) == 0 &&
             fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2)) {
             // lines of padding per row / per plane (tuning knobs DFFT_PAD_ROW, DFFT_PAD_PLANE; measured: profiles/r02)
             const char* pr = getenv("DFFT_PAD_ROW");
@@ -976,10 +981,14 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (ce) mb = atoll(ce);
         const long long plane_bytes = (p->wbuf ? p->wl.plane : n1 * n2) * (long long)elem_bytes(dtype);
         if (mb > 0) {
-            // (with padded 4 MiB planes 63 fit, i.e. 9 chunks of 57: t0 1.40 ms instead of 1.37 with 8 x 64 planes that spill
-            // the cache by a few KiB, but the X pass then still finds the last chunk in the cache: 0.72 vs 0.77 ms)
+            // With padded 4 MiB planes 63 fit, i.e. 9 chunks of 57 at 512^3: t0 1.40 ms instead of 1.37 with 8 x 64 planes that
+            // spill the cache by a few KiB, but the X pass then still finds the last chunk in the cache (0.72 vs 0.77 ms).
+            // Where the padding would add a chunk to a handful (512 x 256 x 256: 2 -> 3) the natural count is kept.
             const long long fit = std::max(1ll, (mb << 20) / plane_bytes);
-            const long long nchunks = (p->xs + fit - 1) / fit;
+            const long long fit_nat = std::max(1ll, (mb << 20) / (n1 * n2 * (long long)elem_bytes(dtype)));
+            long long       nchunks = (p->xs + fit - 1) / fit;
+            const long long nchunks_nat = (p->xs + fit_nat - 1) / fit_nat;
+            if (nchunks_nat < 6) nchunks = nchunks_nat;
             p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
         }
         if (p->chunk_planes >= p->xs) p->chunk_planes = 0;

@@ -24,8 +24,8 @@
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-enum { SEG128_8K = 0, SEG128_4M = 1, SEG128_1K = 2, SEG1K_512K = 3, RUN64K = 4, SEG128_4M_PAD128 = 5, SEG128_4M_PAD1K = 6, SEG128_4M_PAD4K = 7, SEG128_4M_PAD64K = 8, SEG128_8K_PAD = 9, SEG128_ROWPAD_4M = 10, SEG128_ROWPAD_4M_PAD = 11, SEG128_4M_PAD384 = 12, SEG128_4M_PAD640 = 13 };
-static const char* kNames[] = {"seg128@8K", "seg128@4M", "seg128@1K", "seg1K@512K", "run64K", "seg128@4M+128", "seg128@4M+1K", "seg128@4M+4K", "seg128@4M+64K", "seg128@8K+128", "rowpad@4M+64K", "rowpad@4M+64K+128", "seg128@4M+384", "seg128@4M+640"};
+enum { SEG128_8K = 0, SEG128_4M = 1, SEG128_1K = 2, SEG1K_512K = 3, RUN64K = 4, SEG128_4M_PAD128 = 5, SEG128_4M_PAD1K = 6, SEG128_4M_PAD4K = 7, SEG128_4M_PAD64K = 8, SEG128_8K_PAD = 9, SEG128_ROWPAD_4M = 10, SEG128_ROWPAD_4M_PAD = 11, SEG128_4M_PAD384 = 12, SEG128_4M_PAD640 = 13, SEG128_1M = 14, SEG128_1M_ROT = 15, SEG128_4M_ROT3 = 16, SEG128_512K = 17, SEG128_512K_ROT = 18 };
+static const char* kNames[] = {"seg128@8K", "seg128@4M", "seg128@1K", "seg1K@512K", "run64K", "seg128@4M+128", "seg128@4M+1K", "seg128@4M+4K", "seg128@4M+64K", "seg128@8K+128", "rowpad@4M+64K", "rowpad@4M+64K+128", "seg128@4M+384", "seg128@4M+640", "seg128@1M", "seg128@1M rot3", "seg128@4M rot3", "seg128@512K", "seg128@512K rot3"};
 
 // element offset of point k (0..7) of thread tid in tile t, for a 512^3 volume of 16-byte elements
 template <int PAT> __device__ __forceinline__ size_t addr(unsigned t, int tid, int k) {
@@ -37,6 +37,17 @@ template <int PAT> __device__ __forceinline__ size_t addr(unsigned t, int tid, i
     } else if (PAT == SEG128_4M) {             // tile = (y, b): [idx][y][b*8 + c]
         const unsigned y = t >> 6, b = t & 63;
         return ((size_t)idx * 512 + y) * 512 + b * 8 + c;
+    } else if (PAT == SEG128_1M || PAT == SEG128_1M_ROT) {   // X pass at P = 4: [x][ys = 128][512], tile = (yy, b)
+        const unsigned y = (t >> 6) & 127, b = t & 63;
+        const unsigned bb = PAT == SEG128_1M_ROT ? (b + 3u * (unsigned)idx) & 63u : b;  // rows rotated by 3 lines per plane
+        return ((size_t)idx * 128 + y) * 512 + bb * 8 + c;
+    } else if (PAT == SEG128_512K || PAT == SEG128_512K_ROT) {   // P = 8: [x][ys = 64][512]
+        const unsigned y = (t >> 6) & 63, b = t & 63;
+        const unsigned bb = PAT == SEG128_512K_ROT ? (b + 3u * (unsigned)idx) & 63u : b;
+        return ((size_t)idx * 64 + y) * 512 + bb * 8 + c;
+    } else if (PAT == SEG128_4M_ROT3) {
+        const unsigned y = t >> 6, b = t & 63;
+        return ((size_t)idx * 512 + y) * 512 + ((b + 3u * (unsigned)idx) & 63u) * 8 + c;
     } else if (PAT == SEG128_8K_PAD) {         // Y pass on rows padded by one line: [x][idx][520]
         const unsigned x = t >> 6, b = t & 63;
         return ((size_t)x * 512 + idx) * 520 + b * 8 + c;
@@ -141,5 +152,10 @@ int main() {
     run<RUN64K, SEG128_8K_PAD>();
     run<SEG128_ROWPAD_4M, RUN64K>();
     run<SEG128_ROWPAD_4M_PAD, RUN64K>();
+    run<SEG128_4M_ROT3, RUN64K>();
+    run<SEG128_1M, RUN64K>();
+    run<SEG128_1M_ROT, RUN64K>();
+    run<SEG128_512K, RUN64K>();
+    run<SEG128_512K_ROT, RUN64K>();
     return 0;
 }
