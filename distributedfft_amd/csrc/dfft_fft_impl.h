@@ -308,9 +308,11 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
     static constexpr int TWLIVE = TwLive<P, P::S - 1, Tune::TWPOW>::value;
     // Twiddles live in VGPRs when the per-thread set is small (<= 16 distinct complex); otherwise in an LDS copy of the
-    // table, unless that would push the block past 128 KiB of LDS (then they are read through L1/L2).
+    // table, unless that would push the block past the 160 KiB of a CU (then they are read through L1/L2).  (Budget raised
+    // from 128 KiB in round 2: with the table in LDS the 1000-point column kernels spill 150 B instead of 550 B and run at
+    // 3.1 instead of 2.1 TB/s; the 2048-point half-line tile + table use exactly 160 KiB.)
     static constexpr int TWMODE = TWLIVE <= 16 ? TW_REG
-                                  : ((size_t)LDS_ELEMS * G * sizeof(V) + P::N * sizeof(typename VecTraits<V>::W) <= 128 * 1024
+                                  : ((size_t)LDS_ELEMS * G * sizeof(V) + P::N * sizeof(typename VecTraits<V>::W) <= 160 * 1024
                                          ? TW_LDS : TW_GLOBAL);
     static constexpr int TW_ELEMS = TWMODE == TW_LDS ? P::N : 0;  // in units of W
     // rounded up so that the exchange tile behind the twiddle copy stays 16-byte aligned (odd lengths in fp32)
