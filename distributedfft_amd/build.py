@@ -68,6 +68,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
         units.append((CSRC / "dfft_fft_inst.hip", OBJ / f"dfft_fft_inst_{g}.o", [f"-DDFFT_INST_GROUP={g}"]))
     units.append((CSRC / "dfft_kernels.hip", OBJ / "dfft_kernels.o", []))
     units.append((CSRC / "dfft_generic.hip", OBJ / "dfft_generic.o", []))
+    units.append((CSRC / "dfft_long.hip", OBJ / "dfft_long.o", []))
     for name in ("dfft_plan", "dfft_exchange", "dfft_bootstrap"):
         units.append((CSRC / f"{name}.cpp", OBJ / f"{name}.o", ["-x", "hip"]))
 

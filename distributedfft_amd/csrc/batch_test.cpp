@@ -94,7 +94,7 @@ int main(int argc, char* argv[]) {
     const char* dv = getenv("DFFT_LOCAL_DEVICE");
     HIP_OK(hipSetDevice(dv ? atoi(dv) : 0));
     if (!dfft_length_supported(X) || (BATCH_DIM == 2 && !dfft_length_supported(Y))) {
-        fprintf(stderr, "Error! unsupported length (single-pass range: 7-smooth lengths up to 4096)\n");
+        fprintf(stderr, "Error! unsupported length (7-smooth lengths up to 4096, or products of two tuned lengths above)\n");
         return 3;
     }
 

@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "dfft_internal.h"
+#include "dfft_long.h"
 
 namespace dfft {
 
@@ -117,10 +118,20 @@ struct SlabLayout {
     long long pitch, plane;
 };
 
+// scratch slab of the plan that is executing on this thread (long-axis plans; set by dfft_execute)
+static thread_local void* t_plan_scratch = nullptr;
+
 // contiguous rows: `rows` FFTs of length n; row pitch n, or (lin/lout given) rows_per_plane rows per plane in the given layouts
 static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s,
                     long long first_row = 0, int hints = 0, double scale = 1.0, const SlabLayout* lin = nullptr,
-                    const SlabLayout* lout = nullptr, long long rows_per_plane = 0) {
+                    const SlabLayout* lout = nullptr, long long rows_per_plane = 0, void* long_scratch_buf = nullptr) {
+    if (n > 4096) {  // beyond the single-pass range: four-step decomposition (dfft_long.hip), plain contiguous rows only
+        if (lin || lout) return fail(DFFT_EINVAL, "fft_rows: long axes use the natural layout");
+        const size_t off = (size_t)first_row * n * elem_bytes(dtype);
+        void*        scr = long_scratch_buf ? long_scratch_buf : (t_plan_scratch ? t_plan_scratch : long_scratch((size_t)rows * n * elem_bytes(dtype), s));
+        if (!scr) return fail(DFFT_EHIP, "fft_rows: cannot allocate the scratch buffer of the four-step transform");
+        return long_fft((const char*)in + off, (char*)out + off, n, 1, rows, dtype, dir, scale, scr, s);
+    }
     const void* tw = nullptr;
     int         rc = get_twiddles(n, dtype, &tw);
     if (rc) return rc;
@@ -197,6 +208,10 @@ struct dfft_plan_s {
     // data rate (tools/membench4.hip, profiles/r02/README.md section 1).  Caller-visible buffers keep the reference layouts.
     void*                   wbuf = nullptr;
     SlabLayout              wl{0, 0};
+    // an axis beyond the single-pass range (> 4096 points, dfft_long.hip): the plan runs the un-fused stage structure (only
+    // contiguous rows and natural-layout columns need the four-step form then) and owns the scratch slab it needs
+    bool                    long_axis = false;
+    void*                   lbuf = nullptr;
 };
 
 static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
@@ -244,6 +259,12 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
                     long long nx, int hints = 0, const SlabLayout* lay_in = nullptr, const SlabLayout* lay_out = nullptr) {
     const int       n1 = (int)p->N[1];
     const long long n2 = p->N[2];
+    if (n1 > 4096) {  // four-step form: natural layout on both sides only (long-axis plans run un-fused)
+        auto natural = [&](const SlabLayout* l) { return !l || (l->pitch == n2 && l->plane == (long long)n1 * n2); };
+        if (use_packed || !natural(lay_in) || !natural(lay_out)) return fail(DFFT_EINVAL, "Y pass: a long axis needs the natural layout");
+        const size_t off = (size_t)x0 * n1 * n2 * elem_bytes(p->dtype);
+        return long_fft((const char*)in + off, (char*)out + off, n1, n2, nx, p->dtype, p->direction, 1.0, p->lbuf, p->stream);
+    }
     const void*     tw = nullptr;
     int             rc = get_twiddles(n1, p->dtype, &tw);
     if (rc) return rc;
@@ -641,7 +662,12 @@ int dfft_device_pci_bus_id(int device, char* buf, int len) {
     return DFFT_OK;
 }
 
-int dfft_length_supported(long long n) { return (n > 0 && n < (1ll << 30) && fft_length_supported((int)n)) ? 1 : 0; }
+int dfft_length_supported(long long n) {
+    if (n <= 0 || n >= (1ll << 30)) return 0;
+    if (fft_length_supported((int)n)) return 1;
+    int a, b;
+    return long_split(n, &a, &b) ? 1 : 0;  // two-pass (four-step) plans above 4096
+}
 
 int dfft_proper_device_count(const long long N[3], int ini_devices_in_rank, int nranks, int rank, int real_devices,
                              int* new_total, int* new_in_rank) {
@@ -802,7 +828,12 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (!dfft_length_supported(n))
             return fail(DFFT_EUNSUPPORTED, "dfft_plan_create: FFT length " + std::to_string(n) + " has no gfx950 plan");
 
+    const bool long_axis = n0 > 4096 || n1 > 4096 || n2 > 4096;
+    if (long_axis && (flags & DFFT_PLAN_NATURAL))
+        return fail(DFFT_EUNSUPPORTED, "dfft_plan_create: natural-order plans need single-pass axis lengths (<= 4096)");
+    if (long_axis) flags = (flags | DFFT_PLAN_UNFUSED) & ~DFFT_PLAN_OVERLAP;  // the four-step axes run in the reference's stage structure
     dfft_plan_s* p = new dfft_plan_s;
+    p->long_axis = long_axis;
     p->N[0] = n0;
     p->N[1] = n1;
     p->N[2] = n2;
@@ -993,8 +1024,17 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         }
         if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
+    if (p->long_axis) {
+        p->chunk_planes = 0;  // the four-step passes work on the whole slab
+        e = hipMalloc(&p->lbuf, (size_t)p->max_count * elem_bytes(dtype));
+        if (e != hipSuccess) {
+            dfft_plan_destroy(p);
+            return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+        }
+    }
     // warm the twiddle caches so execute never allocates
     for (long long n : {n0, n1, n2}) {
+        if (n > 4096) continue;  // long axes: their factors' tables are built on first use
         const void* tw;
         int         rc = get_twiddles((int)n, dtype, &tw);
         if (rc) {
@@ -1022,9 +1062,11 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     plan->host_timed = sync;
     plan->timed = sync || !(exec_flags & DFFT_EXEC_NO_TIMING);
     if (!plan->timed && (exec_flags & DFFT_EXEC_PRINT)) return fail(DFFT_EINVAL, "dfft_execute: PRINT needs stage timing");
+    t_plan_scratch = plan->lbuf;
     int rc = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
              : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
                                                : execute_backward(plan, sync);
+    t_plan_scratch = nullptr;
     if (rc) return rc;
     // host-synchronised executes have drained the stream: an asynchronous exchange that timed out on a dead or slow peer
     // must not let the caller print timings / use results (the reference-named wrapper always executes this way)
@@ -1113,6 +1155,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
     if (plan->wbuf) hipFree(plan->wbuf);
+    if (plan->lbuf) hipFree(plan->lbuf);
     delete plan;
     return DFFT_OK;
 }
@@ -1137,6 +1180,11 @@ int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long
     if (!in || !out || batch < 0 || width < 1) return fail(DFFT_EINVAL, "dfft_fft1d_cols: bad arguments");
     if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_cols: unsupported length");
     if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_cols: no HIP device visible (no CPU fallback)");
+    if (n > 4096) {
+        void* scr = long_scratch((size_t)batch * n * width * elem_bytes(dtype), (hipStream_t)stream);
+        if (!scr) return fail(DFFT_EHIP, "dfft_fft1d_cols: cannot allocate the scratch buffer of the four-step transform");
+        return long_fft(in, out, n, width, batch, dtype, direction, 1.0, scr, (hipStream_t)stream);
+    }
     const void* tw = nullptr;
     int         rc = get_twiddles((int)n, dtype, &tw);
     if (rc) return rc;

@@ -76,7 +76,9 @@ int dfft_device_count(void);
  * (HIP_VISIBLE_DEVICES renumbers them per process).  Returns 0 and a NUL-terminated string in buf[0..len). */
 int dfft_device_pci_bus_id(int device, char* buf, int len);
 /* 1 if FFT length n is supported: any product of 2, 3, 5, 7 up to 4096 (tuned plans for the lengths listed in
- * csrc/dfft_plans.h, a run-time-scheduled kernel for the rest) -- the single-pass range of the reference's generator. */
+ * csrc/dfft_plans.h, a run-time-scheduled kernel for the rest) -- the single-pass range of the reference's generator --
+ * and, above 4096, every product of two tuned lengths up to 2^24 (two-pass "four-step" plans, csrc/dfft_long.hip; the
+ * reference's multi-upload plans, templateFFT.cpp:3972-4106).  3D plans with such an axis run the un-fused stage structure. */
 int dfft_length_supported(long long n);
 
 /* ---- slab bookkeeping: pure host arithmetic, callable without a GPU ------------------------------------------------ */

@@ -26,7 +26,7 @@ def _run(exe, args, tmp_path):
 
 # input re = i + 1 up to 2^26: the round trip's absolute error scales with that magnitude (the reference's own table shows
 # 2.8e-13 ... 1.2e-10 for its radix-5 rows); 1e-6 absolute = 1.5e-14 relative to the largest input
-@pytest.mark.parametrize("x", [512, 243, 625, 2187, 3125, 343, 1000])
+@pytest.mark.parametrize("x", [512, 243, 625, 2187, 3125, 343, 1000, 8192, 15625, 131072])
 def test_test_1d_rows_of_every_radix_family(gpu, tmp_path, x):
     out, row = _run("Test_1D", [x, 1, 1, 20, 0], tmp_path)
     assert "1 - FFT + iFFT C2C 1D in double precision LUT" in out and re.search(r"FFT: %dx\d+x1 Buffer: " % x, out)
@@ -48,5 +48,5 @@ def test_test_2d_rows(gpu, tmp_path, x, y):
 
 
 def test_unsupported_length_is_refused(gpu, tmp_path):
-    r = subprocess.run([str(LIB / "Test_1D"), "8192", "1", "1", "5", "0"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([str(LIB / "Test_1D"), "8191", "1", "1", "5", "0"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "unsupported length" in r.stderr

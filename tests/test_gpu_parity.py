@@ -239,6 +239,48 @@ def test_execute_without_stage_events(gpu):
     plan.destroy()
 
 
+# ---- axes beyond the single-pass range: four-step plans (dfft_long.hip; reference templateFFT.cpp:3972-4106) ---------------
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("n", [8192, 16384, 6561, 15625, 10000, 65536, 12288])
+def test_long_fft1d_rows_and_cols_vs_numpy(gpu, n, prec):
+    import torch
+    from distributedfft_amd import api
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1, 1, (5, n)) + 1j * rng.uniform(-1, 1, (5, n))
+    xt = torch.from_numpy(x).to(gpu).to(_torch_dtype(prec))
+    ref = np.fft.fft(x)
+    assert _rel_err(api.fft1d_rows(xt, api.FORWARD).cpu().numpy(), ref) < TOL[prec]
+    assert _rel_err(api.fft1d_rows(xt, api.BACKWARD).cpu().numpy(), np.fft.ifft(x) * n) < TOL[prec]
+    y = xt.clone()
+    api.fft1d_rows(y, api.FORWARD, out=y)                      # in place
+    assert _rel_err(y.cpu().numpy(), ref) < TOL[prec]
+    for width in (24, 7):
+        c = rng.uniform(-1, 1, (2, n, width)) + 1j * rng.uniform(-1, 1, (2, n, width))
+        ct = torch.from_numpy(c).to(gpu).to(_torch_dtype(prec))
+        assert _rel_err(api.fft1d_cols(ct, api.FORWARD).cpu().numpy(), np.fft.fft(c, axis=1)) < TOL[prec]
+        assert _rel_err(api.fft1d_cols(ct, api.BACKWARD).cpu().numpy(), np.fft.ifft(c, axis=1) * n) < TOL[prec]
+
+
+@pytest.mark.parametrize("N,P", [((8192, 16, 24), 1), ((16, 8192, 24), 1), ((24, 16, 8192), 1), ((8192, 32, 16), 4),
+                                 ((32, 8192, 16), 2), ((16, 36, 6561), 3), ((10000, 10, 10), 2)])
+def test_long_axis_3d_plans_vs_fftn(gpu, N, P):
+    """A 3D plan with one axis above 4096 runs the reference's (un-fused) stage structure with four-step transforms on that
+    axis: forward against numpy.fft.fftn in the [yy][z][kx] slab layout, then backward / N back to the input."""
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=sum(N) + P)
+    ref = so.fftn_reference(x, P)          # numpy.fft.fftn, split into the devices' [yy][z][kx] slabs
+    inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    outs, _ = _run_plans(gpu, N, P, "f64", x, +1, 0, inputs)
+    scale = max(np.abs(r).max() for r in ref)
+    for d in range(P):
+        got = outs[d][:ref[d].size].reshape(ref[d].shape)
+        assert np.abs(got - ref[d]).max() / scale < 1e-11, (N, P, d)
+    bouts, _ = _run_plans(gpu, N, P, "f64", None, -1, 0, [r for r in ref])
+    for g in range(P):
+        got = bouts[g][:inputs[g].size].reshape(inputs[g].shape) / float(n0 * n1 * n2)
+        assert np.abs(got - inputs[g]).max() < 1e-10, (N, P, g)
+
+
 def test_unsupported_length_fails_loudly(gpu):
     import torch
     from distributedfft_amd import api

@@ -98,10 +98,12 @@ def test_bad_arguments_return_codes(native_lib):
     # last Y slab empty: N1 = 9 over 4 devices -> 3,3,3,0 (the reference cannot run this either)
     assert native_lib.dfft_exchange_layout(16, 9, 8, 4, 0, 1, None, None, None, None) != 0
     assert b"last slab" in native_lib.dfft_last_error()
-    # tuned plans, then 7-smooth lengths served by the run-time-scheduled kernel (<= 4096), then everything else
+    # tuned plans, then 7-smooth lengths served by the run-time-scheduled kernel (<= 4096), then two-pass (four-step) lengths
+    # = products of two tuned lengths up to 4096^2 ... 2^24, then everything else
     for n, ok in [(512, 1), (768, 1), (1024, 1), (2048, 1), (256, 1), (7, 1), (343, 1),
                   (4096, 1), (1000, 1), (640, 1), (3072, 1), (20, 1), (2401, 1),
-                  (11, 0), (13, 0), (8192, 0), (4100, 0), (22, 0), (1, 0), (0, 0), (-4, 0)]:
+                  (8192, 1), (16384, 1), (6561, 1), (15625, 1), (10000, 1), (131072, 1), (1 << 22, 1),
+                  (11, 0), (13, 0), (8191, 0), (4100, 0), (22, 0), (1, 0), (0, 0), (-4, 0), (2 * 4099, 0), (1 << 25, 0)]:
         assert native_lib.dfft_length_supported(n) == ok
 
 
