@@ -212,6 +212,15 @@ struct dfft_plan_s {
     // contiguous rows and natural-layout columns need the four-step form then) and owns the scratch slab it needs
     bool                    long_axis = false;
     void*                   lbuf = nullptr;
+    // Placement tuning of the hand-over buffer (forward, single GPU).  Which physical pages a 2 GiB buffer lands on decides
+    // whether the X pass runs at 0.71 or 0.77 ms (same virtual addresses, same code: tools/placement_probe.py,
+    // profiles/r02/experiments/placement_probe.log), so the first executes of a plan try up to three allocations -- every one
+    // of them a complete, correct transform -- time their X pass with a pair of events and keep the fastest.  DFFT_TUNE=0: off.
+    std::vector<void*>      w_cand;          // allocations still alive while tuning (w_cand[w_cur] == wbuf)
+    int                     w_cur = 0, w_runs = 0;   // current candidate, timed executes it has had
+    bool                    w_tuning = false, w_pending = false;
+    float                   w_ms[3] = {1e30f, 1e30f, 1e30f};
+    hipEvent_t              w_ev[2] = {nullptr, nullptr};
 };
 
 static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
@@ -398,6 +407,52 @@ struct StageClock {
         if (rc_) return rc_;  \
     } while (0)
 
+// Placement tuning (dfft_plan_s::w_cand): called at the start of a forward execute while tuning is on.
+static void w_tune_finish(dfft_plan_s* p) {
+    int best = 0;
+    for (int i = 1; i < (int)p->w_cand.size(); ++i)
+        if (p->w_ms[i] < p->w_ms[best]) best = i;
+    for (int i = 0; i < (int)p->w_cand.size(); ++i)
+        if (i != best && p->w_cand[i]) (void)hipFree(p->w_cand[i]);
+    p->wbuf = p->w_cand[best];
+    p->w_cand.assign(1, p->wbuf);
+    p->w_cur = 0;
+    p->w_tuning = false;
+    if (getenv("DFFT_DEBUG"))
+        fprintf(stderr, "[dfft] hand-over buffer placement: X pass %.4f / %.4f / %.4f ms, kept candidate %d\n", p->w_ms[0],
+                p->w_ms[1] > 1e29f ? 0.f : p->w_ms[1], p->w_ms[2] > 1e29f ? 0.f : p->w_ms[2], best);
+}
+static void w_tune_step(dfft_plan_s* p) {
+    if (p->w_pending) {  // the previous execute's X pass
+        float ms = 0;
+        if (hipEventSynchronize(p->w_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, p->w_ev[0], p->w_ev[1]) == hipSuccess) {
+            if (ms < p->w_ms[p->w_cur]) p->w_ms[p->w_cur] = ms;
+        }
+        p->w_pending = false;
+        ++p->w_runs;
+    }
+    if (p->w_runs < 2) return;  // two timed executes per candidate
+    // two candidates in different modes: keep the better one; otherwise try a third, then settle
+    const int have = p->w_cur + 1;
+    bool      more = have < 3;
+    if (have == 2) {
+        const float lo = std::min(p->w_ms[0], p->w_ms[1]), hi = std::max(p->w_ms[0], p->w_ms[1]);
+        if (lo < 0.96f * hi) more = false;
+    }
+    if (more) {
+        void* nw = nullptr;
+        if (hipMalloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype)) == hipSuccess) {  // earlier candidates stay allocated
+            p->w_cand.push_back(nw);
+            p->w_cur = have;
+            p->w_runs = 0;
+            p->wbuf = nw;
+            return;
+        }
+        (void)hipGetLastError();
+    }
+    w_tune_finish(p);
+}
+
 static int execute_forward(dfft_plan_s* p, bool sync) {
     const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
     const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
@@ -406,6 +461,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // ---- t0: 2D YZ FFT of every owned plane ----
     // The Z and Y passes run chunk by chunk over groups of planes that fit the 256 MiB Infinity Cache, so the Y pass
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
+    if (p->w_tuning) w_tune_step(p);
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const bool      y_packs = fused && p->exch;
     // where the Z pass puts its rows for the Y pass: the padded work buffer when the plan has one (fused pipelines)
@@ -501,7 +557,13 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     DFFT_TRY(clk.end_stage());
     // ---- t3: X FFT (+ transpose to [yl][N2][N0]) ----
     if (fused) {
+        const bool tune = p->w_tuning && !p->exch && p->wbuf;
+        if (tune) DFFT_HIP_TRY(hipEventRecord(p->w_ev[0], p->stream));
         DFFT_TRY(launch_x(p, xsrc, p->buf2, false, 0, (!p->exch && p->wbuf) ? &zl : nullptr));
+        if (tune) {
+            DFFT_HIP_TRY(hipEventRecord(p->w_ev[1], p->stream));
+            p->w_pending = true;
+        }
     } else {
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, n0, p->ys * n2, p->stream);
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
@@ -1000,6 +1062,13 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                     dfft_plan_destroy(p);
                     return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
                 }
+                if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] plan buffers: in %p out %p bufferDev1 %p work %p\n", in, out, p->buf1, p->wbuf);
+                const char* te = getenv("DFFT_TUNE");
+                if (direction == DFFT_FORWARD && !p->exch && !(te && *te == '0') && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
+                    hipEventCreate(&p->w_ev[1]) == hipSuccess) {
+                    p->w_cand.assign(1, p->wbuf);
+                    p->w_tuning = true;
+                }
             }
         }
     }
@@ -1154,7 +1223,14 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
-    if (plan->wbuf) hipFree(plan->wbuf);
+    if (!plan->w_cand.empty()) {
+        for (void* w : plan->w_cand)
+            if (w) hipFree(w);
+    } else if (plan->wbuf) {
+        hipFree(plan->wbuf);
+    }
+    for (auto& e : plan->w_ev)
+        if (e) hipEventDestroy(e);
     if (plan->lbuf) hipFree(plan->lbuf);
     delete plan;
     return DFFT_OK;
