@@ -1048,7 +1048,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         // (cache-resident problems do not reach HBM's channels: 256^3 is 6 % slower with the extra buffer).
         const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
         const bool      pays = (pe && *pe == '1') || (plane_b % (1ll << 20) == 0 && p->xs * plane_b > (256ll << 20));
-        if (!(pe && *pe == '0') && pays && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && (n2 % line) == 0 &&
+        // (single GPU only: with an exchange the X pass reads the receive buffer, whose layout is the wire format)
+        if (!(pe && *pe == '0') && pays && !p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && (n2 % line) == 0 &&
             fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2)) {
             // lines of padding per row / per plane (tuning knobs DFFT_PAD_ROW, DFFT_PAD_PLANE; measured: profiles/r02)
             const char* pr = getenv("DFFT_PAD_ROW");
