@@ -275,3 +275,9 @@ def test_headline_kernels_do_not_spill():
     for tag, vgpr, scratch, _ in rows:
         assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
         assert vgpr <= 256, f"{tag}: {vgpr} registers (a 512-thread block has 256 per wave)"
+    # the long axes of BASELINE configs 4 and 5 (1024- and 2048-point kernels, fp64 and fp32 column pairs): same rule
+    for group, n in ((5, 1024), (6, 2048)):
+        rows = [r for r in kr.kernel_table(group) if f" N={n} " in r[0] and (r[0].startswith("f64") or r[0].startswith("pair"))]
+        assert len(rows) >= 10, (group, n, len(rows))
+        for tag, vgpr, scratch, _ in rows:
+            assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
