@@ -319,6 +319,8 @@ def main():
     if overlap:
         flags |= api.PLAN_OVERLAP  # exchange parts on a second stream behind the plane-chunked Z+Y passes
     plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
+    if P == 1 and hasattr(plan, "tune"):
+        plan.tune()  # plan-time measurement (FFTW_MEASURE-style, part of plan set-up, before any warm-up or timed step)
 
     # P > 1: the un-overlapped plan is both the diagnostic (full t2) and the referee -- the overlapped pipeline must
     # reproduce its result bit for bit on every rank, otherwise the timed loop falls back to it

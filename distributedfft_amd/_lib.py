@@ -54,6 +54,7 @@ SIGNATURES = {
     "dfft_plan_stream": (_VP, [_VP]),
     "dfft_execute": (C.c_int, [_VP, C.c_uint]),
     "dfft_plan_sync": (C.c_int, [_VP]),
+    "dfft_plan_tune": (C.c_int, [_VP]),
     "dfft_plan_set_scale": (C.c_int, [_VP, C.c_double]),
     "dfft_stage_times": (C.c_int, [_VP, C.POINTER(C.c_double)]),
     "dfft_kernel_times": (C.c_int, [_VP, C.POINTER(C.c_double)]),

@@ -217,6 +217,13 @@ class Plan:
     def sync(self) -> None:
         L.check(L.load().dfft_plan_sync(self.handle), "dfft_plan_sync")
 
+    def tune(self) -> None:
+        """Plan-time measurement (dfft_plan_tune): a few complete forward transforms that settle where the plan's internal
+        hand-over buffer lives; overwrites the result buffer with valid results."""
+        import torch
+        with torch.cuda.device(self.device):
+            L.check(L.load().dfft_plan_tune(self.handle), "dfft_plan_tune")
+
     def set_scale(self, s: float) -> None:
         """Multiply the result of every later execute by s (folded into the X-pass kernel; 1.0 = the reference's
         un-normalised transform)."""

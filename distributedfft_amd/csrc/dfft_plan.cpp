@@ -214,12 +214,14 @@ struct dfft_plan_s {
     void*                   lbuf = nullptr;
     // Placement tuning of the hand-over buffer (forward, single GPU).  Which physical pages a 2 GiB buffer lands on decides
     // whether the X pass runs at 0.71 or 0.77 ms (same virtual addresses, same code: tools/placement_probe.py,
-    // profiles/r02/experiments/placement_probe.log), so the first executes of a plan try up to three allocations -- every one
+    // profiles/r02/experiments/placement_probe.log), so the first executes of a plan try up to five allocations -- every one
     // of them a complete, correct transform -- time their X pass with a pair of events and keep the fastest.  DFFT_TUNE=0: off.
     std::vector<void*>      w_cand;          // allocations still alive while tuning (w_cand[w_cur] == wbuf)
+    std::vector<void*>      w_trash;         // losing candidates: freed at the next dfft_plan_sync / destroy (hipFree drains
+                                             // the device, which must not happen between two timed executes)
     int                     w_cur = 0, w_runs = 0;   // current candidate, timed executes it has had
     bool                    w_tuning = false, w_pending = false;
-    float                   w_ms[3] = {1e30f, 1e30f, 1e30f};
+    float                   w_ms[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     hipEvent_t              w_ev[2] = {nullptr, nullptr};
 };
 
@@ -413,14 +415,15 @@ static void w_tune_finish(dfft_plan_s* p) {
     for (int i = 1; i < (int)p->w_cand.size(); ++i)
         if (p->w_ms[i] < p->w_ms[best]) best = i;
     for (int i = 0; i < (int)p->w_cand.size(); ++i)
-        if (i != best && p->w_cand[i]) (void)hipFree(p->w_cand[i]);
+        if (i != best && p->w_cand[i]) p->w_trash.push_back(p->w_cand[i]);
     p->wbuf = p->w_cand[best];
     p->w_cand.assign(1, p->wbuf);
     p->w_cur = 0;
     p->w_tuning = false;
     if (getenv("DFFT_DEBUG"))
-        fprintf(stderr, "[dfft] hand-over buffer placement: X pass %.4f / %.4f / %.4f ms, kept candidate %d\n", p->w_ms[0],
-                p->w_ms[1] > 1e29f ? 0.f : p->w_ms[1], p->w_ms[2] > 1e29f ? 0.f : p->w_ms[2], best);
+        fprintf(stderr, "[dfft] hand-over buffer placement: X pass %.4f / %.4f / %.4f / %.4f / %.4f ms, kept candidate %d\n", p->w_ms[0],
+                p->w_ms[1] > 1e29f ? 0.f : p->w_ms[1], p->w_ms[2] > 1e29f ? 0.f : p->w_ms[2], p->w_ms[3] > 1e29f ? 0.f : p->w_ms[3],
+                p->w_ms[4] > 1e29f ? 0.f : p->w_ms[4], best);
 }
 static void w_tune_step(dfft_plan_s* p) {
     if (p->w_pending) {  // the previous execute's X pass
@@ -432,11 +435,15 @@ static void w_tune_step(dfft_plan_s* p) {
         ++p->w_runs;
     }
     if (p->w_runs < 2) return;  // two timed executes per candidate
-    // two candidates in different modes: keep the better one; otherwise try a third, then settle
+    // stop as soon as the candidates seen so far are in different modes (the fast one is kept); five draws at most
     const int have = p->w_cur + 1;
-    bool      more = have < 3;
-    if (have == 2) {
-        const float lo = std::min(p->w_ms[0], p->w_ms[1]), hi = std::max(p->w_ms[0], p->w_ms[1]);
+    bool      more = have < 5;
+    if (have >= 2) {
+        float lo = p->w_ms[0], hi = p->w_ms[0];
+        for (int i = 1; i < have; ++i) {
+            lo = std::min(lo, p->w_ms[i]);
+            hi = std::max(hi, p->w_ms[i]);
+        }
         if (lo < 0.96f * hi) more = false;
     }
     if (more) {
@@ -1064,12 +1071,12 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                     return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
                 }
                 if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] plan buffers: in %p out %p bufferDev1 %p work %p\n", in, out, p->buf1, p->wbuf);
+                // placement tuning: armed by dfft_plan_tune() (or from the first execute on with DFFT_TUNE=lazy)
                 const char* te = getenv("DFFT_TUNE");
-                if (direction == DFFT_FORWARD && !p->exch && !(te && *te == '0') && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
-                    hipEventCreate(&p->w_ev[1]) == hipSuccess) {
-                    p->w_cand.assign(1, p->wbuf);
+                p->w_cand.assign(1, p->wbuf);
+                if (direction == DFFT_FORWARD && te && !strcmp(te, "lazy") && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
+                    hipEventCreate(&p->w_ev[1]) == hipSuccess)
                     p->w_tuning = true;
-                }
             }
         }
     }
@@ -1154,9 +1161,34 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     return DFFT_OK;
 }
 
+int dfft_plan_tune(dfft_plan_t plan) {
+    if (!plan) return fail(DFFT_EINVAL, "dfft_plan_tune: null plan");
+    const char* te = getenv("DFFT_TUNE");
+    if (te && *te == '0') return DFFT_OK;
+    // only single-GPU forward plans with a hand-over buffer have anything to measure
+    if (plan->direction != DFFT_FORWARD || plan->exch || !plan->wbuf || plan->w_cand.empty() || (plan->flags & DFFT_PLAN_NATURAL))
+        return DFFT_OK;
+    if (!plan->w_ev[0] && (hipEventCreate(&plan->w_ev[0]) != hipSuccess || hipEventCreate(&plan->w_ev[1]) != hipSuccess))
+        return fail(DFFT_EHIP, "dfft_plan_tune: cannot create events");
+    if (plan->w_cand.size() == 1 && !plan->w_tuning) {  // (re)start
+        for (float& m : plan->w_ms) m = 1e30f;
+        plan->w_cur = 0;
+        plan->w_runs = 0;
+        plan->w_pending = false;
+        plan->w_tuning = true;
+    }
+    for (int i = 0; i < 16 && plan->w_tuning; ++i) {
+        const int rc = dfft_execute(plan, DFFT_EXEC_NO_TIMING);
+        if (rc) return rc;
+    }
+    return dfft_plan_sync(plan);  // also frees the candidates that lost
+}
+
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    for (void* w : plan->w_trash) (void)hipFree(w);
+    plan->w_trash.clear();
     if (plan->comm) return comm_check(plan->comm);
     return DFFT_OK;
 }
@@ -1224,6 +1256,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
+    for (void* w : plan->w_trash) hipFree(w);
     if (!plan->w_cand.empty()) {
         for (void* w : plan->w_cand)
             if (w) hipFree(w);
