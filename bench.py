@@ -319,8 +319,10 @@ def main():
     if overlap:
         flags |= api.PLAN_OVERLAP  # exchange parts on a second stream behind the plane-chunked Z+Y passes
     plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
+    plan_setup = "dfft_plan_create"
     if P == 1 and hasattr(plan, "tune"):
         plan.tune()  # plan-time measurement (FFTW_MEASURE-style, part of plan set-up, before any warm-up or timed step)
+        plan_setup += " + dfft_plan_tune (plan-time placement measurement, before warm-up; results bit-identical without it)"
 
     # P > 1: the un-overlapped plan is both the diagnostic (full t2) and the referee -- the overlapped pipeline must
     # reproduce its result bit for bit on every rank, otherwise the timed loop falls back to it
@@ -546,7 +548,7 @@ def main():
             "vs_baseline": None, "dtype": "f64" if args.precision == "fp64" else "f32", "data": "synthetic",
             "config": {"workload": f"{n0}x{n1}x{n2} C2C {args.precision} forward, slab decomposition over {P} GPU(s), "
                                    f"{'fused' if not args.unfused else 'unfused'} pipeline, input resident in HBM",
-                       "parallelism": f"slab{P}",
+                       "parallelism": f"slab{P}", "plan_setup": plan_setup,
                        "exchange": "none (P=1)" if P == 1 else
                                    ("hipIpc peer copies + rendezvous barriers (DFFT_EXCHANGE=ipc)" if exchange_backend == "ipc"
                                     else "hipIpc peer copies + stream-ordered flag words (DFFT_EXCHANGE=ipc-async)"

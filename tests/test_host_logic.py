@@ -242,11 +242,15 @@ def test_exchange_pieces_tile_the_buffers_and_pair_up(native_lib):
     assert checked >= 40
 
 
+def c_sample(d):
+    return d["cpu_baseline"]["sample"]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r01/bench_512_fp64_P1.json is a verbatim bench.py line from the GPU box: the fields the driver's contract
+    """profiles/r02/bench_512_fp64_P1.json is a verbatim bench.py line from the GPU box: the fields the driver's contract
     names, the roofline object priced against the 8 TB/s HBM peak, and the CPU baseline timed on the same box."""
     import json
-    d = json.loads((ROOT / "profiles" / "r01" / "bench_512_fp64_P1.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r02" / "bench_512_fp64_P1.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -257,6 +261,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-2
     assert 0.99 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05    # PMC bytes per launch vs algorithmic bytes
+    assert 1.9 < r["zy_stage"]["traffic"] / r["algorithmic_bytes_per_launch"] < 2.1   # t0: the intermediate crosses the fabric twice
+    assert "512^3" in c_sample(d)                                              # CPU leg on the metric's own configuration
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "GFlops/s"
     assert d["value"] / c["value"] > 100   # reported next to each other, not a target
