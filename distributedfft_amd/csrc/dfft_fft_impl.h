@@ -578,6 +578,112 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dual half-line tiles.  A length whose full-line column tile (8 x 16 B) does not fit the LDS (2048 points: 256 KiB) runs
+// on 4-column tiles; fft_tiles_kernel then reads and writes 64-byte half lines.  Here a workgroup owns the TWO tiles that
+// share the 128-byte lines of a row segment: every thread loads and stores the element of column c AND of column c + CB
+// (a wave touches whole lines), and the two 4-column transforms go through the one LDS tile one after the other while the
+// other half waits in registers.  Fast path of the transposing store only (forward X pass; no ragged tile, no uneven slab),
+// staged per half through the same LDS; everything else stays on fft_tiles_kernel.
+template <class V, class P, int CB> struct DualGeom {
+    using W = typename VecTraits<V>::W;
+    static constexpr int    LANES = VecTraits<V>::LANES, OPAD = LANES == 2 ? 2 : 1;
+    static constexpr size_t TW_BYTES = ((size_t)P::N * sizeof(W) + 15) / 16 * 16;
+    static constexpr bool   PADROW = (size_t)(P::N + OPAD) * CB * sizeof(V) + TW_BYTES <= 160 * 1024;
+    static constexpr int    ROW = PADROW ? P::N + OPAD : P::N;  // in units of W; CB * LANES rows
+    static constexpr size_t LDS_BYTES = TW_BYTES + (size_t)ROW * CB * sizeof(V);
+    static_assert(LDS_BYTES <= 160 * 1024, "dual tiles: tile + twiddle table must fit the CU's LDS");
+};
+template <class V, class P, int CB, int DIR, bool NT>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * P::T), amdgpu_waves_per_eu(1)))
+fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
+                      AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
+                      double scale) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr int E = P::E, T = P::T, GT = CB * T, N = P::N, LANES = VT::LANES;
+    static_assert(P::S > 1 && GT <= 1024, "dual tiles: multi-stage plans, one workgroup per tile pair");
+    // Staged image of the transposing store, one row per scalar column.  Where the LDS has room next to the twiddle table the
+    // rows are padded (N + OPAD elements: affine addresses, immediate offsets); at N = 2048 in fp64 tile + table are exactly
+    // 160 KiB, so the rows stay N long and row s is rotated by ROT * s elements instead.  Measured
+    // (profiles/r02/experiments/dual_tiles.log): any rotation that is not a multiple of 8 memory elements gives 4.8-4.9 TB/s,
+    // multiples of 8 (8, 16) 4.5.
+    using DG = DualGeom<V, P, CB>;
+    constexpr bool PADROW = DG::PADROW;
+    constexpr int  ROW = DG::ROW, ROT = LANES;
+    auto img_at = [](int col, int e) -> int {  // element e of scalar column col, in units of W
+        if constexpr (PADROW) return col * ROW + e;
+        else return col * N + ((e + ROT * col) & (N - 1));
+    };
+    constexpr size_t TW_BYTES = ((size_t)N * sizeof(W) + 15) / 16 * 16;
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    W* ldstw = reinterpret_cast<W*>(dfft_smem);
+    V* lds = reinterpret_cast<V*>(dfft_smem + TW_BYTES);
+    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    for (int i = tid; i < N; i += GT) {
+        W w = tw[i];
+        if (DIR < 0) w.y = -w.y;
+        ldstw[i] = w;
+    }
+    __syncthreads();
+    // The launcher guarantees imap.blk % T == 0: the block a point j + T*k falls into depends on k alone, so its
+    // offset splits into a wave-uniform term per k and ONE per-thread term -- no per-point address registers next to the two
+    // register sets.  (Writing the accesses as uniform base + 32-bit per-thread byte offset did not make the compiler pick the
+    // SGPR-base form of the global instructions; it cost 7-41 spilled registers instead.)
+    long long iuni[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int ib = (T * k) / imap.blk;
+        iuni[k] = block_term(imap, ib) + (long long)(T * k - ib * imap.blk) * imap.stride;
+    }
+    const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+    constexpr int ON = N / LANES;  // memory elements per scalar column of the staged image
+    static_assert((N & (N - 1)) == 0 && (ON % GT == 0 || GT % ON == 0), "staged store: power-of-two geometry");
+    // Variants measured and dropped (profiles/r02/experiments/dual_tiles.log, X pass of 2048 x 1024 x 512 fp64: this 4.8 TB/s,
+    // one 4-column tile per workgroup 4.0): half 1 loaded underneath the transform of half 0 -- 3.9, the other half line has
+    // left the L2 by then; half 1 on the point index j ^ 1 so that a wave instruction fetches whole lines, values sorted into
+    // their halves by selects -- 4.4 with 21 spilled registers.  Plain (non-transposing) column passes gain nothing from
+    // pairing (3.3 vs 3.6 TB/s: the XCD-aware tile order of fft_tiles_kernel already brings the half lines together in one L2
+    // and that kernel keeps two workgroups' worth of loads in flight), so launch_plan pairs tiles for the transposing store only.
+    const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
+    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        const GV*      ip = in + (long long)a * itile.a_stride + (long long)b * (2 * CB) * itile.b_stride + ithr;
+        GV*            op = out + (long long)a * otile.a_stride + (long long)b * (2 * CB) * otile.b_stride;
+        V v0[E], v1[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            v0[k] = VT::from_g(gload<NT>(ip + iuni[k]));
+            v1[k] = VT::from_g(gload<NT>(ip + iuni[k] + (long long)CB * imap.cstride));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            V* v = h == 0 ? v0 : v1;
+            run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1>(v, ldstw, lds, j, c);
+            W* img = reinterpret_cast<W*>(lds);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+#pragma unroll
+                for (int l = 0; l < LANES; ++l) {
+                    const int col = c * LANES + l;
+                    img[img_at(col, j + T * k)] = VT::lane(cscale(v[k], sc), l);
+                }
+            __syncthreads();
+            GV* oh = op + (long long)h * CB * LANES * omap.cstride;  // omap.cstride: distance between SCALAR columns
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const int lin = tid + GT * k;
+                const int col = lin / ON;
+                const GV  r = *reinterpret_cast<const GV*>(img + img_at(col, (lin % ON) * LANES));
+                gstore<NT>(oh + (long long)col * omap.cstride + (lin % ON), r);
+            }
+            __syncthreads();  // the image is read before the next half's exchange overwrites the tile
+        }
+    }
+}
+
 struct DeviceInfo {
     int cus;
 };
@@ -647,6 +753,36 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     return hipSuccess;
 }
 
+template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(const FftLaunch& L, hipStream_t stream) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr size_t LDS_BYTES = DualGeom<V, P, CB>::LDS_BYTES;
+    auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT>;
+    static bool attr_set[64] = {false};
+    int         dev = 0;
+    hipError_t  e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * P::T);
+        attr_set[dev] = true;
+    }
+    const long long tiles_per_a = L.ncols / (2 * CB), ntiles = L.na * tiles_per_a;
+    if (ntiles <= 0) return hipSuccess;
+    if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    long long grid = device_info().cus;
+    if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
+    if (grid > ntiles) grid = ntiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * P::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
+    e = hipGetLastError();
+    if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * P::T);
+    return hipSuccess;
+}
+
 template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };
 
 // Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex).  Tiles up to
@@ -709,6 +845,19 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStre
         using TT = TuneTransposedStore;
         constexpr bool can_stage = can_stage_store<V, P>();
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
+        // half-line tiles (2048 points) with the transposing store: pair the two tiles of every 128-byte line in one workgroup
+        // when columns are adjacent in memory on the input side (forward X pass)
+        constexpr bool can_dual = P::S > 1 && sizeof(V) == 16 && 2 * CBC * sizeof(V) == 128 && (P::N & (P::N - 1)) == 0 && (P::N / VecTraits<V>::LANES) % (CBC * P::T) == 0 &&
+                                  (size_t)P::N * CBC * sizeof(V) + (size_t)P::N * sizeof(typename VecTraits<V>::W) <= 160 * 1024;
+        if constexpr (can_dual) {
+            static const bool no_dual = [] {  // DFFT_NO_DUAL=1: A/B switch for measurements
+                const char* e = getenv("DFFT_NO_DUAL");
+                return e && *e && *e != '0';
+            }();
+            const bool transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
+            if (!no_dual && !general && transposed && L.imap.blk % P::T == 0 && L.ncols % (2 * CBC) == 0 && L.imap.cstride == 1 && L.itile.b_stride == 1)
+                return L.dir > 0 ? launch_dual<V, P, CBC, +1, true>(L, stream) : launch_dual<V, P, CBC, -1, true>(L, stream);
+        }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
             if constexpr (can_stage)

@@ -125,6 +125,9 @@ SHAPES = [
     # long X / Y axes: staged transposed store with 16 points per thread (1024), half-line tiles (2048; fp32: staged
     # column pairs), 24 points per thread (768), and the 512-point headline kernels on a small slab
     ((2048, 4, 16), 1), ((1024, 6, 32), 2), ((768, 4, 16), 1), ((8, 2048, 16), 1), ((512, 8, 32), 1),
+    # 2048-point X pass: paired half-line tiles (fft_dual_tiles_kernel) over per-peer blocks of the exchange buffer (P = 2, 4),
+    # and a column count that is not a multiple of a tile pair (single 4-column tiles)
+    ((2048, 4, 16), 2), ((2048, 8, 8), 4), ((2048, 3, 4), 1),
     # lengths without a tuned plan (run-time-scheduled kernel) on every axis, with pack / transposed store / uneven slabs
     ((20, 36, 40), 1), ((20, 36, 40), 4), ((45, 50, 18), 4), ((1000, 6, 8), 2), ((8, 640, 12), 2), ((4096, 2, 8), 1),
     ((16, 24, 1536), 2), ((60, 64, 20), 8),

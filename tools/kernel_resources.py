@@ -1,5 +1,5 @@
 """Register / scratch / LDS usage of the FFT kernels of one instantiation group (no GPU needed): compiles
-csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* directives of every fft_tiles_kernel.
+csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* directives of every fft_tiles_kernel / fft_dual_tiles_kernel.
 
   python tools/kernel_resources.py <group> [filter]        e.g.  python tools/kernel_resources.py 3 N=512
 
@@ -27,15 +27,20 @@ def kernel_table(group: int):
             raise RuntimeError(r.stderr[-3000:])
         asm = next(Path(tmp).glob("*gfx950.s")).read_text()
     rows = []
-    for m in re.finditer(r"^(_ZN4dfft16fft_tiles_kernel\w+): ", asm, re.M):
+    for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel)\w+): ", asm, re.M):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
         mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)EEEv", name)
-        if not mm:
+        md = re.match(r"_ZN4dfft21fft_dual_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])EEEv", name)
+        if mm:
+            ty = TYPES.get(mm.group(1), mm.group(1))
+            tag = (f"{ty} N={mm.group(2)} E={mm.group(3)} CB={mm.group(4)} G={mm.group(5)} dir={'-1' if mm.group(6) == 'n1' else '1'} "
+                   f"general={mm.group(7)} {mm.group(8)}")
+        elif md:  # paired half-line tiles (transposing store of the 2048-point X pass)
+            ty = TYPES.get(md.group(1), md.group(1))
+            tag = f"{ty} N={md.group(2)} E={md.group(3)} CB=2x{md.group(4)} G=1 dir={'-1' if md.group(5) == 'n1' else '1'} general=0 DualTiles"
+        else:
             continue
-        ty = TYPES.get(mm.group(1), mm.group(1))
-        tag = (f"{ty} N={mm.group(2)} E={mm.group(3)} CB={mm.group(4)} G={mm.group(5)} dir={'-1' if mm.group(6) == 'n1' else '1'} "
-               f"general={mm.group(7)} {mm.group(8)}")
 
         def field(key):
             f = re.search(rf"\.amdhsa_{key} (\d+)", body)
