@@ -741,11 +741,6 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     if (L.blocks_per_cu_limit > 0 && L.blocks_per_cu_limit < bpc) bpc = L.blocks_per_cu_limit;
     long long grid = (long long)device_info().cus * bpc;
     if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
-    if (L.round_query) {  // what one grid-stride round of this variant covers (nothing is launched)
-        L.round_query[0] = grid * G;
-        L.round_query[1] = CB * VecTraits<V>::LANES;
-        return hipSuccess;
-    }
     if (grid > nblocks_needed) grid = nblocks_needed;
     if (grid < 1) return hipSuccess;
     (void)hipGetLastError();  // drop any stale error of this thread (other libraries share the runtime)
@@ -779,11 +774,6 @@ template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(con
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     long long grid = device_info().cus;
     if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
-    if (L.round_query) {
-        L.round_query[0] = grid;
-        L.round_query[1] = 2 * CB * VT::LANES;
-        return hipSuccess;
-    }
     if (grid > ntiles) grid = ntiles;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * P::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,

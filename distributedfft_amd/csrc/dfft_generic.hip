@@ -198,7 +198,6 @@ template <class V> hipError_t launch_generic_t(const FftLaunch& Lin, hipStream_t
 }  // namespace
 
 hipError_t launch_generic(const FftLaunch& L, hipStream_t stream) {
-    if (L.round_query) return hipSuccess;  // no round geometry reported (query stays 0): the plan keeps its even split
     if (L.dtype == F64) return launch_generic_t<double2>(L, stream);
     if (L.dtype == F32) return launch_generic_t<float2>(L, stream);
     return hipErrorInvalidValue;

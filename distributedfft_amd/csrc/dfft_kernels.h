@@ -53,9 +53,6 @@ struct FftLaunch {
                                       // kernel running concurrently on another stream)
     int         grid_limit;           // > 0: cap the persistent grid at this many workgroups (HBM writes run faster from
                                       // fewer concurrent writers, profiles/r02/README.md section 1; tuning knob)
-    long long*  round_query;          // non-null: launch nothing; report [0] = tiles the persistent grid of the selected
-                                      // variant takes per grid-stride round on this device, [1] = columns per tile (1 for
-                                      // rows).  The plan sizes its cache chunks in whole rounds with it (dfft_plan.cpp).
 };
 enum {
     FFT_HINT_STREAM_IN = 1,   // input is read once and must not displace the cache-resident chunk: non-temporal loads

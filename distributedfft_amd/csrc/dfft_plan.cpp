@@ -120,9 +120,6 @@ struct SlabLayout {
 
 // scratch slab of the plan that is executing on this thread (long-axis plans; set by dfft_execute)
 static thread_local void* t_plan_scratch = nullptr;
-// non-null while dfft_plan_create asks the launch layer for the round geometry of the Z / Y passes (FftLaunch::round_query):
-// fft_rows / launch_y then build their launch as usual but nothing runs
-static thread_local long long* t_round_query = nullptr;
 
 // contiguous rows: `rows` FFTs of length n; row pitch n, or (lin/lout given) rows_per_plane rows per plane in the given layouts
 static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s,
@@ -164,7 +161,6 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
     }
     static const int zgrid = env_grid("DFFT_Z_GRID");
     L.grid_limit = zgrid;
-    L.round_query = t_round_query;
     return check_launch(launch_fft(L, s), "fft_rows");
 }
 
@@ -195,8 +191,6 @@ struct dfft_plan_s {
     ExchangeDesc xd;
     ExchangeDesc xd2;        // DFFT_PLAN_NATURAL: the second (Y -> X) exchange
     long long   chunk_planes;  // planes per Z+Y chunk (Infinity-Cache blocking); 0 = whole slab in one launch pair
-    long long   chunk_first = 0;  // > 0: the first chunk has this many planes (the remainder goes first, so that the X pass
-                                  // still finds a full-size last chunk in the cache)
     // DFFT_PLAN_OVERLAP (forward, P > 1): exchange parts on a second stream behind the plane-chunked Z+Y passes
     long long               part_planes = 0;  // planes per exchange part, identical on every rank; 0 = overlap off
     hipStream_t             stream2 = nullptr;
@@ -225,8 +219,6 @@ struct dfft_plan_s {
     std::vector<void*>      w_cand;          // allocations still alive while tuning (w_cand[w_cur] == wbuf)
     std::vector<void*>      w_trash;         // losing candidates: freed at the next dfft_plan_sync / destroy (hipFree drains
                                              // the device, which must not happen between two timed executes)
-    size_t                  w_slack = 0;     // DFFT_W_SLACK_MB (placement experiments): extra bytes behind the buffer; the
-                                             // data then starts DFFT_W_OFFSET bytes into the allocation (read per execute)
     int                     w_cur = 0, w_runs = 0;   // current candidate, timed executes it has had
     bool                    w_tuning = false, w_pending = false;
     float                   w_ms[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
@@ -331,7 +323,6 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.ncols = (int)n2;
     static const int ygrid = env_grid("DFFT_Y_GRID");
     L.grid_limit = ygrid;
-    L.round_query = t_round_query;
     return check_launch(launch_fft(L, p->stream), "Y pass");
 }
 
@@ -418,12 +409,6 @@ struct StageClock {
         if (rc_) return rc_;  \
     } while (0)
 
-// planes of the Z+Y chunk that starts at plane x0 (cp = planes per chunk; the remainder chunk, if any, comes first)
-static inline long long chunk_len(const dfft_plan_s* p, long long x0, long long cp) {
-    if (x0 == 0 && p->chunk_first > 0 && p->chunk_first < cp) return std::min(p->chunk_first, p->xs);
-    return std::min(cp, p->xs - x0);
-}
-
 // Placement tuning (dfft_plan_s::w_cand): called at the start of a forward execute while tuning is on.
 static void w_tune_finish(dfft_plan_s* p) {
     int best = 0;
@@ -463,7 +448,7 @@ static void w_tune_step(dfft_plan_s* p) {
     }
     if (more) {
         void* nw = nullptr;
-        if (hipMalloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype) + p->w_slack) == hipSuccess) {  // earlier candidates stay allocated
+        if (hipMalloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype)) == hipSuccess) {  // earlier candidates stay allocated
             p->w_cand.push_back(nw);
             p->w_cur = have;
             p->w_runs = 0;
@@ -484,12 +469,6 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // The Z and Y passes run chunk by chunk over groups of planes that fit the 256 MiB Infinity Cache, so the Y pass
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
     if (p->w_tuning) w_tune_step(p);
-    if (p->w_slack && !p->w_tuning && p->w_cand.size() == 1) {  // placement experiments (tools/offset_probe.py)
-        const char* oe = getenv("DFFT_W_OFFSET");
-        size_t      off = oe ? (size_t)atoll(oe) : 0;
-        if (off > p->w_slack) off = p->w_slack;
-        p->wbuf = (char*)p->w_cand[0] + (off & ~(size_t)127);
-    }
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const bool      y_packs = fused && p->exch;
     // where the Z pass puts its rows for the Y pass: the padded work buffer when the plan has one (fused pipelines)
@@ -552,8 +531,8 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    for (long long x0 = 0, nx = 0; x0 < p->xs; x0 += nx) {
-        nx = chunk_len(p, x0, cp);
+    for (long long x0 = 0; x0 < p->xs; x0 += cp) {
+        const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                           (chunked && zsrc != zdst) ? FFT_HINT_STREAM_IN : 0, 1.0, lnat, lz, lz ? n1 : 0));
         if (!sync && p->timed && cp >= p->xs) DFFT_HIP_TRY(hipEventRecord(p->ev[5], p->stream));
@@ -611,8 +590,8 @@ static int execute_natural(dfft_plan_s* p, bool sync) {
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     const bool      hinted = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    for (long long x0 = 0, nx = 0; x0 < p->xs; x0 += nx) {
-        nx = chunk_len(p, x0, cp);
+    for (long long x0 = 0; x0 < p->xs; x0 += cp) {
+        const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, p->buf1, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                           (hinted && zsrc != p->buf1) ? FFT_HINT_STREAM_IN : 0));
         if (p->exch) DFFT_TRY(launch_y(p, p->buf1, p->buf2, true, true, x0, nx, hinted ? FFT_HINT_STREAM_OUT : 0));
@@ -721,8 +700,8 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    for (long long x0 = 0, nx = 0; x0 < p->xs; x0 += nx) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
-        nx = chunk_len(p, x0, cp);
+    for (long long x0 = 0; x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
+        const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
         else if (xw) DFFT_TRY(launch_y(p, p->wbuf, p->wbuf, false, false, x0, nx, 0, &yl, &yl));
         else DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false, x0, nx));
@@ -1086,8 +1065,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             p->wl.pitch = n2 + row_lines * line;
             p->wl.plane = n1 * p->wl.pitch + plane_lines * line;
             if (p->xs * p->wl.plane < (1ll << 31)) {
-                if (const char* se = getenv("DFFT_W_SLACK_MB")) p->w_slack = (size_t)std::max(0ll, atoll(se)) << 20;
-                e = hipMalloc(&p->wbuf, (size_t)p->xs * p->wl.plane * elem_bytes(dtype) + p->w_slack);
+                e = hipMalloc(&p->wbuf, (size_t)p->xs * p->wl.plane * elem_bytes(dtype));
                 if (e != hipSuccess) {
                     dfft_plan_destroy(p);
                     return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
@@ -1103,65 +1081,29 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         }
     }
     {
-        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of planes of the
-        // intermediate (padded planes when the work buffer is in use) that fits, then evened out over the chunks.
-        // DFFT_CHUNK_MB=0 disables, =k overrides the capacity.
+        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of NATURAL planes that
+        // fits, evened out over the chunks -- 8 x 64 planes at 512^3 fp64.  With the padded work buffer such a chunk is a few
+        // KiB larger than the cache; measured (profiles/r02/experiments/chunk_planes_sweep.log, two boxes) that is still the
+        // best size: t0 1.37-1.38 ms against 1.40-1.42 for 9 x 57 (sized on the padded planes), 60 or 63 planes, and the X pass
+        // runs no slower behind it.  t0 follows the chunk count (~9 us per Z+Y launch pair) and is worst just above a
+        // power-of-two size (40 planes: 1.63 ms); chunks of whole grid-stride rounds (56 / 60 planes) gain nothing.
+        // Planes of 8 MiB and more (1024-point Y columns) keep one plane of head-room: 1024^3 15 instead of 16 planes t0 12.6 ->
+        // 12.4 ms, 2048 x 1024 x 512 31 instead of 32 planes 12.5 -> 12.1 ms; smaller planes want the full count (512^3 fp64 64
+        // planes, fp32 128 planes 0.80 -> 0.74 ms, 384^3 4 x 96; profiles/r02/experiments/chunk_shapes.log).
+        // DFFT_CHUNK_MB=0 disables, =k overrides the capacity; DFFT_CHUNK_PLANES=n sets the chunk size directly (experiments).
         long long   mb = 256;
         const char* ce = getenv("DFFT_CHUNK_MB");
         if (ce) mb = atoll(ce);
-        const long long plane_bytes = (p->wbuf ? p->wl.plane : n1 * n2) * (long long)elem_bytes(dtype);
         if (mb > 0) {
-            // With padded 4 MiB planes 63 fit, i.e. 9 chunks of 57 at 512^3: t0 1.40 ms instead of 1.37 with 8 x 64 planes that
-            // spill the cache by a few KiB, but the X pass then still finds the last chunk in the cache (0.72 vs 0.77 ms).
-            // Where the padding would add a chunk to a handful (512 x 256 x 256: 2 -> 3) the natural count is kept.
-            const long long fit = std::max(1ll, (mb << 20) / plane_bytes);
-            const long long fit_nat = std::max(1ll, (mb << 20) / (n1 * n2 * (long long)elem_bytes(dtype)));
-            long long       nchunks = (p->xs + fit - 1) / fit;
-            const long long nchunks_nat = (p->xs + fit_nat - 1) / fit_nat;
-            if (nchunks_nat < 6) nchunks = nchunks_nat;
+            const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
+            long long       fit = std::max(1ll, (mb << 20) / plane_b);
+            if (plane_b >= (8ll << 20) && fit > 1) --fit;
+            const long long nchunks = (p->xs + fit - 1) / fit;
             p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
-            // Whole rounds: the passes run on persistent grids, so a chunk whose rows / column tiles are not a multiple of
-            // what the grid takes per grid-stride round ends in a round that only a fraction of the workgroups work in
-            // (57 planes at 512^3 fp64: 14.25 rounds of both passes, i.e. 15).  Ask the launch layer for the round geometry of
-            // the two passes as this plan launches them and keep the chunks to multiples of q planes; the remainder of the
-            // slab goes FIRST (the X pass then still finds a full-size last chunk in the cache).  DFFT_CHUNK_ROUNDS=0: off;
-            // DFFT_CHUNK_PLANES=n: explicit chunk size (experiments).
-            const char* re = getenv("DFFT_CHUNK_ROUNDS");
-            const char* pe2 = getenv("DFFT_CHUNK_PLANES");
-            if (pe2 && atoll(pe2) > 0) {
-                p->chunk_planes = atoll(pe2);
-                if (!getenv("DFFT_CHUNK_SMALL_LAST")) p->chunk_first = p->xs % p->chunk_planes;
-            } else if (!(re && *re == '0') && p->chunk_planes < p->xs && !p->long_axis) {
-                long long qz[2] = {0, 0}, qy[2] = {0, 0};
-                const SlabLayout nat{n2, n1 * n2};
-                const SlabLayout *lw = p->wbuf ? &p->wl : nullptr, *lnat = lw ? &nat : nullptr;
-                const long long   probe = std::min<long long>(p->xs, 2);
-                t_round_query = qz;
-                int qrc = fft_rows(p->in, p->buf1, (int)n2, probe * n1, dtype, direction, p->stream, 0, FFT_HINT_STREAM_IN, 1.0, lnat, lw, lw ? n1 : 0);
-                t_round_query = qy;
-                if (!qrc) qrc = launch_y(p, p->buf1, p->buf1, true, false, 0, probe, 0, lw, lw);
-                t_round_query = nullptr;
-                if (!qrc && qz[0] > 0 && qy[0] > 0 && qy[1] > 0) {
-                    auto gcd = [](long long a, long long b) { while (b) { long long t = a % b; a = b; b = t; } return a; };
-                    const long long tiles_per_plane = (n2 + qy[1] - 1) / qy[1];
-                    const long long pz = qz[0] / gcd(qz[0], n1), py = qy[0] / gcd(qy[0], tiles_per_plane);  // planes per whole number of rounds
-                    const long long q = pz / gcd(pz, py) * py;
-                    const long long cap = nchunks == nchunks_nat ? fit_nat : fit;
-                    if (q > 0 && q <= cap && p->xs % q == 0) {
-                        const long long cp_max = cap / q * q;
-                        const long long nch = (p->xs + cp_max - 1) / cp_max;
-                        long long       cp = ((p->xs + nch - 1) / nch + q - 1) / q * q;  // evened out, then up to a multiple of q
-                        if (cp > cp_max) cp = cp_max;
-                        p->chunk_planes = cp;
-                        p->chunk_first = p->xs % cp;
-                        if (getenv("DFFT_DEBUG"))
-                            fprintf(stderr, "[dfft] Z+Y chunks: rounds of %lld rows / %lld tiles of %lld columns -> %lld-plane quantum, %lld planes per chunk (first %lld)\n",
-                                    qz[0], qy[0], qy[1], q, cp, p->chunk_first ? p->chunk_first : cp);
-                    }
-                }
-            }
         }
-        if (p->chunk_planes >= p->xs) p->chunk_planes = 0, p->chunk_first = 0;
+        const char* cpe = getenv("DFFT_CHUNK_PLANES");
+        if (cpe && atoll(cpe) > 0) p->chunk_planes = atoll(cpe);
+        if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
     if (p->long_axis) {
         p->chunk_planes = 0;  // the four-step passes work on the whole slab

@@ -5,6 +5,7 @@ csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* direc
 
 A kernel that spills (scratch > 0) or loses occupancy shows up here long before it shows up in a benchmark: the 16- and
 24-point-per-thread column kernels sit within a few registers of the 256-VGPR budget of a 512-thread block."""
+import os
 import re
 import subprocess
 import sys
@@ -22,6 +23,7 @@ def kernel_table(group: int):
     with tempfile.TemporaryDirectory() as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
                f"-DDFFT_INST_GROUP={group}", "-c", str(CSRC / "dfft_fft_inst.hip"), "-o", "inst.o", "-save-temps"]
+        cmd += os.environ.get("DFFT_KR_FLAGS", "").split()  # extra -D switches for A/B inventories
         r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-3000:])
