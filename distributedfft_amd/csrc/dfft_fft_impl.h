@@ -23,6 +23,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dfft_butterfly.h"
 #include "dfft_kernels.h"
@@ -197,7 +198,8 @@ enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 // PH = 2: the tile (N x CB elements) is twice what the LDS holds, so every exchange runs in two phases -- first the threads
 // of columns [0, CB/2), then those of [CB/2, CB) -- through one half-size buffer.  HBM accesses keep full 128-byte lines
 // (all CB columns of a row segment are loaded/stored together); only the LDS issue slots double.
-template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW, int PH = 1>
+// TWS: stride of the twiddle table behind twr in TW_LDS / TW_GLOBAL mode (2: the table of a transform twice as long)
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW, int PH = 1, int TWS = 1>
 __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W* twr, V* lds, int j, int c) {
     using SI = StageInfo<P, S, TWPOW>;
     using W = typename VecTraits<V>::W;
@@ -209,11 +211,11 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
         for (int r = 0; r < R; ++r) u[r] = v[q + r * B];
         if constexpr (S > 0) {
             if constexpr (TWMODE == TW_LDS) {
-                const int m = ((j + q * T) % NS) * (P::N / (NS * R));
+                const int m = ((j + q * T) % NS) * (TWS * P::N / (NS * R));
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[r * m]);
             } else if constexpr (TWMODE == TW_GLOBAL) {
-                const int m = ((j + q * T) % NS) * (P::N / (NS * R));
+                const int m = ((j + q * T) % NS) * (TWS * P::N / (NS * R));
 #pragma unroll
                 for (int r = 1; r < R; ++r) {
                     W w = twr[r * m];
@@ -244,7 +246,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
     if constexpr (S + 1 < P::S) {
 #ifdef DFFT_DBG_NOEXCH
         // measurement builds only (tools/kbench): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
         return;
 #endif
         if constexpr (PH == 1) {
@@ -282,7 +284,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
                 }
             }
         }
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
     }
 }
 
@@ -684,6 +686,102 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Full-line column tiles for a length N = 2 * NH whose own full-line tile does not fit the LDS (2048 points: 256 KiB) but whose
+// half does: the first radix-2 stage is done decimation-in-frequency AT LOAD TIME.  Thread j of a column holds the points
+// n = j + T k and n + NH (k < E; PH = the NH-point plan, E T = NH) -- exactly the two inputs of every first-stage butterfly --
+//     a[n] = x[n] + x[n + NH]                  -> even outputs  X[2m]     = DFT_NH(a)[m]
+//     b[n] = (x[n] - x[n + NH]) * W_N^n        -> odd  outputs  X[2m + 1] = DFT_NH(b)[m]
+// and the two NH-point transforms go through the one (NH x CB) LDS tile one after the other while the other half waits in
+// registers.  Every HBM access is a full 128-byte line on both sides (the half-line kernel of fft_tiles_kernel moves 64-byte
+// segments), with 2 E loads per thread in flight.  W_N^{j + T k} = W_N^j * W_N^{T k}: one per-thread factor times a
+// wave-uniform one, so the stage needs no table of its own; the NH-point stages read the even entries of the N-point table
+// from an LDS copy.  Fast path only (no ragged tile, no uneven slab, natural or packed maps whose blocks are multiples of
+// T / 2 T points); the transposing store of the forward X pass stays on fft_dual_tiles_kernel.
+template <class V, class PH, int CB> struct Dif2Geom {
+    using W = typename VecTraits<V>::W;
+    static constexpr size_t TW_BYTES = ((size_t)2 * PH::N * sizeof(W) + 15) / 16 * 16;  // the whole N-point table
+    static constexpr size_t LDS_BYTES = TW_BYTES + (size_t)PH::N * CB * sizeof(V);
+    static_assert(LDS_BYTES <= 160 * 1024, "DIF-split tiles: half tile + twiddle table must fit the CU's LDS");
+};
+// BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
+// which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(1)))
+fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
+                      AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
+                      double scale) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr int E = PH::E, T = PH::T, GT = CB * T, NH = PH::N, N = 2 * NH;
+    static_assert(PH::S > 1 && E * T == NH && GT <= 1024, "DIF-split tiles: multi-stage half plan, one workgroup per tile");
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    W* ldstw = reinterpret_cast<W*>(dfft_smem);  // N entries; the NH-point stages use every second one
+    V* lds = reinterpret_cast<V*>(dfft_smem + Dif2Geom<V, PH, CB>::TW_BYTES);
+    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    for (int i = tid; i < N; i += GT) {
+        W w = tw[i];
+        if (DIR < 0) w.y = -w.y;
+        ldstw[i] = w;
+    }
+    __syncthreads();
+    // Multi-block sides: the launcher guarantees imap.blk % T == 0 and omap.blk % (2 T) == 0, so the block a point falls into
+    // depends on k alone -- a wave-uniform 32-bit term per k (computed once) plus ONE per-thread term.  Plain sides: k * step.
+    unsigned iuni[BIN ? 2 * E : 1], ouni[BOUT ? E : 1];
+    if constexpr (BIN) {
+#pragma unroll
+        for (int kk = 0; kk < 2 * E; ++kk) {
+            const int ib = (T * kk) / imap.blk;
+            iuni[kk] = (unsigned)(block_term(imap, ib) + (long long)(T * kk - ib * imap.blk) * imap.stride);
+        }
+    }
+    if constexpr (BOUT) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int ob = (2 * T * k) / omap.blk;
+            ouni[k] = (unsigned)(block_term(omap, ob) + (long long)(2 * T * k - ob * omap.blk) * omap.stride);
+        }
+    }
+    const long long istep = (long long)T * imap.stride, ostep = (long long)(2 * T) * omap.stride;
+    auto in_off = [&](int kk) -> long long {  // points j + T kk, kk < 2 E
+        if constexpr (BIN) return (long long)iuni[kk];
+        else return kk * istep;
+    };
+    auto out_off = [&](int k) -> long long {  // output rows 2 j + h + 2 T k
+        if constexpr (BOUT) return (long long)ouni[k];
+        else return k * ostep;
+    };
+    const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
+    const long long othr = (long long)(2 * j) * omap.stride + (long long)c * omap.cstride;
+    const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        const GV*      ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride + ithr;
+        GV*            op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride + othr;
+        V v0[E], v1[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            v0[k] = VT::from_g(gload<NTL>(ip + in_off(k)));
+            v1[k] = VT::from_g(gload<NTL>(ip + in_off(k + E)));
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const V sum = cadd(v0[k], v1[k]);
+            const V dif = csub(v0[k], v1[k]);
+            v0[k] = sum;
+            v1[k] = cmul(dif, ldstw[j + T * k]);  // W_N^{j + T k}
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            V* v = h == 0 ? v0 : v1;
+            run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, 2>(v, ldstw, lds, j, c);
+#pragma unroll
+            for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
+        }
+    }
+}
+
 struct DeviceInfo {
     int cus;
 };
@@ -783,6 +881,36 @@ template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(con
     return hipSuccess;
 }
 
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB>::LDS_BYTES;
+    auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT>;
+    static bool attr_set[64] = {false};
+    int         dev = 0;
+    hipError_t  e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * PH::T);
+        attr_set[dev] = true;
+    }
+    const long long tiles_per_a = L.ncols / CB, ntiles = L.na * tiles_per_a;
+    if (ntiles <= 0) return hipSuccess;
+    if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    long long grid = device_info().cus;
+    if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
+    if (grid > ntiles) grid = ntiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * PH::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
+    e = hipGetLastError();
+    if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * PH::T);
+    return hipSuccess;
+}
+
 template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };
 
 // Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex).  Tiles up to
@@ -830,7 +958,8 @@ template <class V, class P> hipError_t launch_rows(const FftLaunch& L, hipStream
     return launch_variant<V, P, 1, GR, -1, false>(L, stream);
 }
 
-template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
+// PH: plan of the half length (N / 2 points) for lengths whose non-transposing column passes run DIF-split (void: none)
+template <class V, class P, class PH = void> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
     constexpr int CBC = cols_per_tile<V, P>();
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
     if (!Lin.cols) return hipErrorInvalidValue;  // rows: launch_rows
@@ -857,6 +986,28 @@ template <class V, class P> hipError_t launch_plan(const FftLaunch& Lin, hipStre
             const bool transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
             if (!no_dual && !general && transposed && L.imap.blk % P::T == 0 && L.ncols % (2 * CBC) == 0 && L.imap.cstride == 1 && L.itile.b_stride == 1)
                 return L.dir > 0 ? launch_dual<V, P, CBC, +1, true>(L, stream) : launch_dual<V, P, CBC, -1, true>(L, stream);
+        }
+        if constexpr (!std::is_void<PH>::value) {
+            // full-line tiles through the DIF split whenever both sides keep the 8 (16 fp32) columns of a line together
+            constexpr int CBF = 128 / (int)sizeof(V);
+            static_assert(2 * PH::N == P::N && CBF * PH::T <= 1024, "half plan of the wrong length");
+            static const bool no_dif2 = [] {  // DFFT_NO_DIF2=1: A/B switch for measurements
+                const char* e = getenv("DFFT_NO_DIF2");
+                return e && *e && *e != '0';
+            }();
+            const bool lines = L.imap.cstride == 1 && L.omap.cstride == 1 && L.itile.b_stride == 1 && L.otile.b_stride == 1;
+            const bool even = L.ncols % CBF == 0 && L.imap.last_delta == 0 && L.omap.last_delta == 0;
+            const bool sin = (L.hints & FFT_HINT_STREAM_IN) != 0, sout = (L.hints & FFT_HINT_STREAM_OUT) != 0;
+            if (!no_dif2 && lines && even && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0) {
+                if (L.dir > 0) {
+                    if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true>(L, stream);
+                    if (sin) return launch_dif2<V, PH, CBF, +1, true, false, true, true>(L, stream);
+                    return launch_dif2<V, PH, CBF, +1, false, false, true, true>(L, stream);
+                }
+                if (sin) return launch_dif2<V, PH, CBF, -1, true, false, true, true>(L, stream);
+                if (sout) return launch_dif2<V, PH, CBF, -1, false, true, true, true>(L, stream);
+                return launch_dif2<V, PH, CBF, -1, false, false, true, true>(L, stream);
+            }
         }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);

@@ -28,17 +28,21 @@ template <int N> struct PlanRows32 : PlanFor32<N> {};
 template <> struct PlanRows<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
 template <> struct PlanRows32<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
 
+// Half plan for the DIF-split full-line column tiles (launch_plan): 2048-point columns run as two 1024-point transforms
+template <int N> struct PlanHalf { using type = void; };
+template <> struct PlanHalf<2048> { using type = PlanFor<1024>::type; };
+
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
     if (!L.cols) {
         if (L.dtype == F64) return launch_rows<double2, typename PlanRows<N>::type>(L, stream);
         if (L.dtype == F32) return launch_rows<float2, typename PlanRows32<N>::type>(L, stream);
         return hipErrorInvalidValue;
     }
-    if (L.dtype == F64) return launch_plan<double2, typename PlanFor<N>::type>(L, stream);
+    if (L.dtype == F64) return launch_plan<double2, typename PlanFor<N>::type, typename PlanHalf<N>::type>(L, stream);
     if (L.dtype == F32) {
         // column launches on even column counts run on column pairs with the fp64 geometry (16 bytes per lane)
         FftLaunch Lp;
-        if (make_pair_launch<typename PlanFor<N>::type>(L, Lp)) return launch_plan<cpair, typename PlanFor<N>::type>(Lp, stream);
+        if (make_pair_launch<typename PlanFor<N>::type>(L, Lp)) return launch_plan<cpair, typename PlanFor<N>::type, typename PlanHalf<N>::type>(Lp, stream);
         return launch_plan<float2, typename PlanFor32<N>::type>(L, stream);
     }
     return hipErrorInvalidValue;

@@ -128,6 +128,9 @@ SHAPES = [
     # 2048-point X pass: paired half-line tiles (fft_dual_tiles_kernel) over per-peer blocks of the exchange buffer (P = 2, 4),
     # and a column count that is not a multiple of a tile pair (single 4-column tiles)
     ((2048, 4, 16), 2), ((2048, 8, 8), 4), ((2048, 3, 4), 1),
+    # 2048-point Y pass: DIF-split full-line tiles (fft_dif2_tiles_kernel) on natural maps (P = 1) and on the packed exchange
+    # layout (P = 2, 4: blocks of 1024 / 512 rows, both directions); 24 columns = 12 fp32 pairs fall back to half-line tiles
+    ((4, 2048, 24), 1), ((8, 2048, 16), 2), ((16, 2048, 8), 4),
     # lengths without a tuned plan (run-time-scheduled kernel) on every axis, with pack / transposed store / uneven slabs
     ((20, 36, 40), 1), ((20, 36, 40), 4), ((45, 50, 18), 4), ((1000, 6, 8), 2), ((8, 640, 12), 2), ((4096, 2, 8), 1),
     ((16, 24, 1536), 2), ((60, 64, 20), 8),

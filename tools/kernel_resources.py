@@ -29,7 +29,7 @@ def kernel_table(group: int):
             raise RuntimeError(r.stderr[-3000:])
         asm = next(Path(tmp).glob("*gfx950.s")).read_text()
     rows = []
-    for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel)\w+): ", asm, re.M):
+    for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel|21fft_dif2_tiles_kernel)\w+): ", asm, re.M):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
         mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)EEEv", name)
@@ -41,6 +41,13 @@ def kernel_table(group: int):
         elif md:  # paired half-line tiles (transposing store of the 2048-point X pass)
             ty = TYPES.get(md.group(1), md.group(1))
             tag = f"{ty} N={md.group(2)} E={md.group(3)} CB=2x{md.group(4)} G=1 dir={'-1' if md.group(5) == 'n1' else '1'} general=0 DualTiles"
+        elif "fft_dif2_tiles_kernel" in name:  # DIF-split full-line tiles (non-transposing 2048-point column passes)
+            mh = re.match(r"_ZN4dfft21fft_dif2_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])ELb([01])E", name)
+            if not mh:
+                continue
+            ty = TYPES.get(mh.group(1), mh.group(1))
+            tag = (f"{ty} N={2 * int(mh.group(2))} E={2 * int(mh.group(3))} CB={mh.group(4)} G=1 dir={'-1' if mh.group(5) == 'n1' else '1'} "
+                   f"general=0 Dif2Tiles ntl={mh.group(6)} nts={mh.group(7)}")
         else:
             continue
 
