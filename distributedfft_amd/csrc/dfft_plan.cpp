@@ -220,6 +220,11 @@ struct dfft_plan_s {
     std::vector<void*>      w_trash;         // losing candidates: freed at the next dfft_plan_sync / destroy (hipFree drains
                                              // the device, which must not happen between two timed executes)
     int                     w_cur = 0, w_runs = 0;   // current candidate, timed executes it has had
+    int                     w_skip = 8;              // executes of the current candidate still to be ignored: the first ~8
+                                                     // executes after an idle gap run the X pass 20 us faster and t0 40 us slower
+                                                     // (profiles/r02/experiments/drift_probe.log), and a fresh buffer's first
+                                                     // execute is not representative either
+    float                   w_t[3] = {0.f, 0.f, 0.f};  // the current candidate's timed X passes (the median is kept)
     bool                    w_tuning = false, w_pending = false;
     float                   w_ms[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     hipEvent_t              w_ev[2] = {nullptr, nullptr};
@@ -427,14 +432,21 @@ static void w_tune_finish(dfft_plan_s* p) {
 }
 static void w_tune_step(dfft_plan_s* p) {
     if (p->w_pending) {  // the previous execute's X pass
-        float ms = 0;
-        if (hipEventSynchronize(p->w_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, p->w_ev[0], p->w_ev[1]) == hipSuccess) {
-            if (ms < p->w_ms[p->w_cur]) p->w_ms[p->w_cur] = ms;
-        }
+        float ms = 1e30f;
+        if (hipEventSynchronize(p->w_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, p->w_ev[0], p->w_ev[1]) != hipSuccess) ms = 1e30f;
         p->w_pending = false;
-        ++p->w_runs;
+        if (p->w_skip > 0) {
+            --p->w_skip;
+        } else {
+            p->w_t[p->w_runs < 3 ? p->w_runs : 2] = ms;
+            ++p->w_runs;
+        }
     }
-    if (p->w_runs < 2) return;  // two timed executes per candidate
+    if (p->w_runs < 3) return;  // three timed executes per candidate, the median counts
+    {
+        float a = p->w_t[0], b = p->w_t[1], c = p->w_t[2];
+        p->w_ms[p->w_cur] = std::max(std::min(a, b), std::min(std::max(a, b), c));
+    }
     // stop as soon as the candidates seen so far are in different modes (the fast one is kept); five draws at most
     const int have = p->w_cur + 1;
     bool      more = have < 5;
@@ -444,7 +456,7 @@ static void w_tune_step(dfft_plan_s* p) {
             lo = std::min(lo, p->w_ms[i]);
             hi = std::max(hi, p->w_ms[i]);
         }
-        if (lo < 0.96f * hi) more = false;
+        if (lo < 0.95f * hi) more = false;  // the two modes are 7-8 % apart (0.70-0.72 vs 0.76-0.78 ms at 512^3 fp64)
     }
     if (more) {
         void* nw = nullptr;
@@ -452,6 +464,7 @@ static void w_tune_step(dfft_plan_s* p) {
             p->w_cand.push_back(nw);
             p->w_cur = have;
             p->w_runs = 0;
+            p->w_skip = 3;
             p->wbuf = nw;
             return;
         }
@@ -1178,10 +1191,11 @@ int dfft_plan_tune(dfft_plan_t plan) {
         for (float& m : plan->w_ms) m = 1e30f;
         plan->w_cur = 0;
         plan->w_runs = 0;
+        plan->w_skip = 8;
         plan->w_pending = false;
         plan->w_tuning = true;
     }
-    for (int i = 0; i < 16 && plan->w_tuning; ++i) {
+    for (int i = 0; i < 40 && plan->w_tuning; ++i) {
         const int rc = dfft_execute(plan, DFFT_EXEC_NO_TIMING);
         if (rc) return rc;
     }

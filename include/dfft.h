@@ -157,12 +157,14 @@ void* dfft_plan_stream(dfft_plan_t plan); /* hipStream_t the plan enqueues on */
 int dfft_execute(dfft_plan_t plan, unsigned exec_flags);
 /* Wait for the plan's stream. */
 int dfft_plan_sync(dfft_plan_t plan);
-/* Optional plan-time measurement (the FFTW_MEASURE of this library; no counterpart in the reference): runs up to a dozen
+/* Optional plan-time measurement (the FFTW_MEASURE of this library; no counterpart in the reference): runs up to three dozen
  * complete forward transforms of the plan's current input -- the result buffer is overwritten with valid results -- and keeps,
  * of up to five allocations of the plan's internal hand-over buffer, the one on which the X pass ran fastest (which physical
- * pages a multi-GiB buffer lands on is worth 8 % of that pass).  A no-op for plans that have no such buffer (P > 1, backward,
- * un-fused, natural-order, cache-resident sizes) and with DFFT_TUNE=0.  DFFT_TUNE=lazy does the same during a plan's first
- * executes instead.  Results are bit-identical with and without tuning. */
+ * pages a multi-GiB buffer lands on is worth 8 % of that pass).  Every candidate is timed in steady state: the first eight
+ * executes after the idle gap of plan creation and the first three on a fresh buffer are ignored, the median of the next three
+ * counts.  A no-op for plans that have no such buffer (P > 1, backward, un-fused, natural-order, cache-resident sizes) and
+ * with DFFT_TUNE=0.  DFFT_TUNE=lazy does the same during a plan's first executes instead.  Results are bit-identical with and
+ * without tuning. */
 int dfft_plan_tune(dfft_plan_t plan);
 /* Multiply the result of every later execute by s (e.g. 1/N for a normalised transform: heFFTe's scale::full, the
  * reference's scale_element pass in 3dmpifft_roc, kernel_func.cpp:102-157).  Folded into the X-pass kernel's store, so it

@@ -245,6 +245,43 @@ def test_execute_without_stage_events(gpu):
     plan.destroy()
 
 
+def test_plan_tune_keeps_results_bit_identical(gpu):
+    """dfft_plan_tune (plan-time placement measurement of the hand-over buffer): a plan that owns such a buffer -- planes a
+    multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- runs its candidates and produces bit for bit what
+    the un-tuned plan produces, before, during (every tuning execute is a complete transform) and after tuning."""
+    import torch
+    from distributedfft_amd import api
+    N = (512, 256, 256)
+    n = N[0] * N[1] * N[2]
+    g = torch.Generator(device=gpu)
+    g.manual_seed(7)
+    a = torch.complex(torch.rand(n, generator=g, device=gpu, dtype=torch.float64) * 2 - 1,
+                      torch.rand(n, generator=g, device=gpu, dtype=torch.float64) * 2 - 1)
+    b0, b1 = torch.zeros_like(a), torch.zeros_like(a)
+    p0 = api.Plan(*N, a, b0, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+    p0.execute(api.EXEC_NO_TIMING)
+    p0.sync()
+    p1 = api.Plan(*N, a, b1, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+    p1.tune()
+    assert torch.equal(b0, b1)            # the last tuning execute left a complete result
+    b1.zero_()
+    p1.execute(api.EXEC_NO_TIMING)
+    p1.sync()
+    assert torch.equal(b0, b1)
+    p1.tune()                             # a second call restarts the measurement
+    p1.execute()
+    assert len(p1.stage_times()) == 4 and torch.equal(b0, b1)
+    # spot check against the defining sum (the element-wise full-size checks live in test_gpu_fullsize.py)
+    k = (3, 5, 7)
+    idx = [torch.arange(m, device=gpu, dtype=torch.float64) for m in N]
+    ph = [torch.exp(-2j * np.pi * k[d] * idx[d] / N[d]) for d in range(3)]
+    direct = (((a.reshape(N) @ ph[2]) @ ph[1]) * ph[0]).sum()
+    got = b1[(k[1] * N[2] + k[2]) * N[0] + k[0]]
+    assert abs(complex(direct) - complex(got)) / abs(complex(direct)) < 1e-11
+    p0.destroy()
+    p1.destroy()
+
+
 # ---- axes beyond the single-pass range: four-step plans (dfft_long.hip; reference templateFFT.cpp:3972-4106) ---------------
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 @pytest.mark.parametrize("n", [8192, 16384, 6561, 15625, 10000, 65536, 12288])
