@@ -53,6 +53,9 @@ struct ZyCfgDefault {
     static constexpr int      HANDOFF = 0;        // 0: sc1 stores + sc1 loads, 1: plain + release / acquire fences
     static constexpr bool     PREFETCH = true;    // load the next item before processing the current one
     static constexpr bool     FINE = true;        // tickets alternate Z / Y units (false: all Z units of a block, then all Y units)
+    static constexpr bool     DYNAMIC = true;     // tickets from a global atomic counter (self-balancing); false: static rotation --
+                                                  // workgroup g takes item m * G + (g + m) % G at its step m (no atomic, no broadcast;
+                                                  // needs every workgroup of the grid resident, which the persistent grid guarantees)
     static constexpr bool     IN_NT = true;       // streamed input
     static constexpr bool     OUT_NT = false;     // Y results: plain stores (the X pass finds the tail in the cache)
     static constexpr bool     MATH = true;        // false: data movement only (measurement builds)
@@ -127,7 +130,9 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
         }
         return it;
     };
+    unsigned step = 0;  // static ticket order only
     auto share = [&](unsigned value_of_thread0) -> unsigned {  // broadcast a value held by thread 0
+        if constexpr (!Cfg::DYNAMIC) return value_of_thread0;  // every thread computed it
         if (tid == 0) shw[0] = value_of_thread0;
         __syncthreads();
         const unsigned t = shw[0];
@@ -135,6 +140,11 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
         return t;
     };
     auto take = [&]() -> unsigned {  // thread 0: the next ticket (the atomic's latency is hidden behind the caller's work)
+        if constexpr (!Cfg::DYNAMIC) {
+            const unsigned t = step * gridDim.x + (blockIdx.x + step) % gridDim.x;
+            ++step;
+            return t;
+        }
         return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) : 0u;
     };
     // dependency of a Y unit: all Z units of its plane have published.  wait = false: one poll only.

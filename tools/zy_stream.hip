@@ -70,6 +70,8 @@ struct CfgFence : ZyCfgDefault { static constexpr int HANDOFF = 1; };
 struct CfgNoPF : ZyCfgDefault { static constexpr bool PREFETCH = false; };
 struct CfgCoarse : ZyCfgDefault { static constexpr bool FINE = false; };
 struct CfgOutNT : ZyCfgDefault { static constexpr bool OUT_NT = true; };
+struct CfgStatic : ZyCfgDefault { static constexpr bool DYNAMIC = false; };
+struct CfgStaticFence : ZyCfgDefault { static constexpr bool DYNAMIC = false; static constexpr int HANDOFF = 1; };
 struct CfgSkel : ZyCfgDefault { static constexpr bool MATH = false; };
 struct CfgSkelFence : ZyCfgDefault { static constexpr bool MATH = false; static constexpr int HANDOFF = 1; };
 
@@ -209,6 +211,8 @@ int main(int argc, char** argv) {
         run_variant<ZyCfgDefault>(c, "stream sc1 hand-off", lag, 1);
         run_variant<CfgFence>(c, "stream plain + fences", lag, 1);
     }
+    run_variant<CfgStatic>(c, "stream sc1, static ticket rotation", 16, 1);
+    run_variant<CfgStaticFence>(c, "stream fences, static ticket rotation", 16, 1);
     run_variant<CfgNoPF>(c, "stream sc1, no prefetch", 16, 1);
     run_variant<CfgCoarse>(c, "stream sc1, coarse ticket order", 16, 1);
     run_variant<CfgOutNT>(c, "stream sc1, nt result stores", 16, 1);
