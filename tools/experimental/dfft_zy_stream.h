@@ -1,5 +1,7 @@
-// dfft_zy_stream.h -- EXPERIMENT (not linked into the library, never run on a GPU at the time of writing: round 2 ended with the
-// GPU budget spent; tools/zy_stream.hip is the harness that verifies it against the library kernels and times it).
+// dfft_zy_stream.h -- EXPERIMENT (not linked into the library; tools/zy_stream.hip is the harness that verifies it against the
+// library kernels and times it).  First GPU run (profiles/r02/experiments/zy_stream_first_run.log): every variant bit-identical to
+// the library, none faster than its phase-separated chunks (1.52 ms at best against 1.37 ms); BUNDLE / CHUNK were added after
+// that run and have only been compiled.
 //
 // t0 (batched 2D YZ FFT of every owned plane; reference fftZY, /root/reference/3dmpifft_opt/include/fft_mpi_3d_api.cpp:466-522)
 // as ONE persistent launch in which the Z rows of plane p + LAG and the Y columns of plane p are in flight AT THE SAME TIME.
@@ -17,7 +19,7 @@
 //     tickets ago, so the poll practically never waits -- and transforms its tile in place.
 // The Infinity-Cache working set is LAG planes (LAG = 16: 64 MiB) instead of a 256 MiB chunk, HBM reads (Z) and cache-only
 // traffic (Y) overlap all the time, and there are no launch boundaries inside t0.  Expected from the boundary ceiling:
-// 8.6 GB / 7.5 TB/s = 1.15 ms against 1.37 ms.
+// 8.6 GB / 7.5 TB/s = 1.15 ms against 1.37 ms -- NOT what the first run showed: the mix is slower than the phases.
 //
 // Visibility (MI355X_MICROARCH.md, inter-workgroup hand-off rules): the producer and the consumer of a row are in general on
 // different XCDs, whose L2s are not coherent with each other, and a CU's L1 is never refreshed by other CUs' stores.
@@ -59,6 +61,10 @@ struct ZyCfgDefault {
     static constexpr bool     IN_NT = true;       // streamed input
     static constexpr bool     OUT_NT = false;     // Y results: plain stores (the X pass finds the tail in the cache)
     static constexpr bool     MATH = true;        // false: data movement only (measurement builds)
+    static constexpr int      BUNDLE = 1;         // units per ticket: a workgroup takes BUNDLE consecutive units of one plane and pays the
+                                                  // hand-off cost (drain + release fence + counter / poll + acquire fence) once per bundle
+    static constexpr int      CHUNK = 0;          // > 0: phase order -- all Z bundles of CHUNK planes, then all Y bundles of the same planes
+                                                  // (the library's cache chunks without the launch boundaries; `lag` is ignored)
     static constexpr unsigned TIMEOUT_TICKS = 20u * 1000u * 100u;  // 20 ms of the 100 MHz wall clock
 };
 
@@ -105,28 +111,45 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
         load_twiddles<V, PY, 0, DIR, TWPOW>(twyr, twy, jy);
     }
 
-    const unsigned total = (nplanes + lag) * B;
+    constexpr unsigned K = Cfg::BUNDLE;
+    static_assert(UZ % K == 0 && UY % K == 0, "bundles must tile a plane's units");
+    constexpr unsigned ZB = UZ / K, YB = UY / K, BB = ZB + YB;  // bundles per plane
+    static_assert(!Cfg::FINE || Cfg::CHUNK > 0 || ZB == YB, "alternating tickets need as many Z as Y bundles per plane");
+    constexpr unsigned CH = Cfg::CHUNK > 0 ? (unsigned)Cfg::CHUNK : 1u;
+    const unsigned nchunks = (nplanes + CH - 1) / CH;
+    const unsigned total = Cfg::CHUNK > 0 ? nchunks * CH * BB : (nplanes + lag) * BB;  // tickets (= bundles, some of them empty)
     enum { NONE = 0, ZU = 1, YU = 2 };
-    struct Item {
+    struct Item {  // one bundle: units [unit, unit + K) of `plane`
         unsigned ticket, kind, plane, unit;
     };
     auto decode = [&](unsigned t) -> Item {
         Item it{t, NONE, 0u, 0u};
         if (t >= total) return it;
-        const unsigned b = t / B, r = t - b * B;
+        if constexpr (Cfg::CHUNK > 0) {
+            const unsigned c = t / (CH * BB), r = t - c * (CH * BB);
+            if (r < CH * ZB) {
+                const unsigned pl = c * CH + r / ZB;
+                if (pl < nplanes) it = Item{t, ZU, pl, (r % ZB) * K};
+            } else {
+                const unsigned r2 = r - CH * ZB, pl = c * CH + r2 / YB;
+                if (pl < nplanes) it = Item{t, YU, pl, (r2 % YB) * K};
+            }
+            return it;
+        }
+        const unsigned b = t / BB, r = t - b * BB;
         bool           z;
         unsigned       u;
         if constexpr (Cfg::FINE) {
             z = (r & 1u) == 0u;
             u = r >> 1;
         } else {
-            z = r < UZ;
-            u = z ? r : r - UZ;
+            z = r < ZB;
+            u = z ? r : r - ZB;
         }
         if (z) {
-            if (b < nplanes) it = Item{t, ZU, b, u};
+            if (b < nplanes) it = Item{t, ZU, b, u * K};
         } else if (b >= lag) {
-            it = Item{t, YU, b - lag, u};
+            it = Item{t, YU, b - lag, u * K};
         }
         return it;
     };
@@ -147,7 +170,7 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
         }
         return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) : 0u;
     };
-    // dependency of a Y unit: all Z units of its plane have published.  wait = false: one poll only.
+    // dependency of a Y bundle: all Z units of its plane have published.  wait = false: one poll only.
     auto ready = [&](const Item& it, bool wait) -> bool {
         if (it.kind != YU) return true;
         if (tid == 0) {
@@ -179,53 +202,57 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
     auto wrsrc = [&](unsigned plane) {  // buffer descriptor of one plane of w (offsets inside a plane fit 32 bits)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(w + (long long)plane * w_plane), 0, (int)((size_t)N1 * N2 * sizeof(V)), 0x00020000);
     };
-    auto load_item = [&](const Item& it, V* dst) {
-        if (it.kind == ZU) {
-            const V* ip = in + (long long)it.plane * in_plane + (long long)(it.unit * GR + gz) * N2 + jz;
+    // unit `un` of the bundle's plane
+    auto load_unit = [&](unsigned kind, unsigned plane, unsigned un, V* dst) {
+        if (kind == ZU) {
+            const V* ip = in + (long long)plane * in_plane + (long long)(un * GR + gz) * N2 + jz;
 #pragma unroll
             for (int k = 0; k < E; ++k) dst[k] = gload<Cfg::IN_NT>(ip + TZ * k);
-        } else if (it.kind == YU) {
+        } else if (kind == YU) {
             if constexpr (Cfg::HANDOFF == 0) {
-                const __amdgpu_buffer_rsrc_t rs = wrsrc(it.plane);
+                const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
-                    const unsigned elem = (unsigned)((jy + TY * k) * N2 + it.unit * CB + cy);
+                    const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
                     dst[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
                 }
             } else {
-                const V* ip = w + (long long)it.plane * w_plane + (long long)jy * N2 + it.unit * CB + cy;
+                const V* ip = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
 #pragma unroll
                 for (int k = 0; k < E; ++k) dst[k] = ip[(long long)(TY * k) * N2];
             }
         }
     };
-    auto process = [&](const Item& it, V* v) {
-        if (it.kind == ZU) {
+    // transform + store one unit; `last`: the bundle's last unit publishes (Z)
+    auto process_unit = [&](unsigned kind, unsigned plane, unsigned un, bool last, V* v) {
+        if (kind == ZU) {
             if constexpr (Cfg::MATH) run_stages<V, PZ, 0, DIR, 1, true, true, TW_REG, TWPOW>(v, twzr, lds_row, jz, 0);
             if constexpr (Cfg::HANDOFF == 0) {
-                const __amdgpu_buffer_rsrc_t rs = wrsrc(it.plane);
+                const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
                 for (int k = 0; k < E; ++k) {
-                    const unsigned elem = (unsigned)((it.unit * GR + gz) * N2 + jz + TZ * k);
+                    const unsigned elem = (unsigned)((un * GR + gz) * N2 + jz + TZ * k);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
                 }
             } else {
-                V* op = w + (long long)it.plane * w_plane + (long long)(it.unit * GR + gz) * N2 + jz;
+                V* op = w + (long long)plane * w_plane + (long long)(un * GR + gz) * N2 + jz;
 #pragma unroll
                 for (int k = 0; k < E; ++k) op[TZ * k] = v[k];
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: my rows have left this CU
-            __syncthreads();
-            if (tid == 0) {
-                if constexpr (Cfg::HANDOFF == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_fetch_add(&ctl->done[it.plane], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+            if (last) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the bundle's rows have left this CU
+                __syncthreads();
+                if (tid == 0) {
+                    if constexpr (Cfg::HANDOFF == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(&ctl->done[plane], K, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+                }
             }
-        } else if (it.kind == YU) {
+        } else if (kind == YU) {
             if constexpr (Cfg::MATH) {
                 __syncthreads();  // the LDS rows of an earlier Z unit are no longer read
                 run_stages<V, PY, 0, DIR, CB, false, false, TW_REG, TWPOW>(v, twyr, lds, jy, cy);
             }
-            V* op = w + (long long)it.plane * w_plane + (long long)jy * N2 + it.unit * CB + cy;
+            V* op = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
 #pragma unroll
             for (int k = 0; k < E; ++k) gstore<Cfg::OUT_NT>(op + (long long)(TY * k) * N2, v[k]);
             if constexpr (Cfg::MATH) __syncthreads();  // the tile is no longer read when the next unit scatters
@@ -233,27 +260,41 @@ zy_stream_kernel(const V* in, V* w, ZyCtl* ctl, const V* __restrict__ twz, const
     };
 
     V    v[E], vn[Cfg::PREFETCH ? E : 1];
-    // tickets are taken two items ahead, so that the atomic's round trip overlaps a whole unit of work
+    // tickets are taken two bundles ahead, so that the atomic's round trip overlaps a whole bundle of work
     Item cur = decode(share(take()));
     Item nxt = decode(share(take()));
     if (cur.kind != NONE) {
         if (!ready(cur, true)) return;
-        load_item(cur, v);
+        load_unit(cur.kind, cur.plane, cur.unit, v);
     }
     while (cur.ticket < total) {
         const unsigned t2 = take();
-        bool           loaded = false;
+        // units 0 .. K-2 of the bundle: the next unit belongs to the same bundle, nothing to check
+#pragma unroll 1
+        for (unsigned i = 0; i + 1 < K; ++i) {
+            if (cur.kind == NONE) break;
+            if constexpr (Cfg::PREFETCH) load_unit(cur.kind, cur.plane, cur.unit + i + 1, vn);
+            process_unit(cur.kind, cur.plane, cur.unit + i, false, v);
+            if constexpr (Cfg::PREFETCH) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) v[k] = vn[k];
+            } else {
+                load_unit(cur.kind, cur.plane, cur.unit + i + 1, v);
+            }
+        }
+        // last unit of the bundle: the next unit is the first of the next bundle (prefetched only if its dependency is satisfied)
+        bool loaded = false;
         if constexpr (Cfg::PREFETCH) {
-            if (nxt.kind != NONE && ready(nxt, false)) {  // only when nothing has to be waited for
-                load_item(nxt, vn);
+            if (nxt.kind != NONE && ready(nxt, false)) {
+                load_unit(nxt.kind, nxt.plane, nxt.unit, vn);
                 loaded = true;
             }
         }
-        process(cur, v);
+        if (cur.kind != NONE) process_unit(cur.kind, cur.plane, cur.unit + K - 1, true, v);
         const Item nn = decode(share(t2));
         if (nxt.kind != NONE && !loaded) {
             if (!ready(nxt, true)) return;
-            load_item(nxt, v);
+            load_unit(nxt.kind, nxt.plane, nxt.unit, v);
         } else if constexpr (Cfg::PREFETCH) {
             if (loaded) {
 #pragma unroll

@@ -72,6 +72,15 @@ struct CfgCoarse : ZyCfgDefault { static constexpr bool FINE = false; };
 struct CfgOutNT : ZyCfgDefault { static constexpr bool OUT_NT = true; };
 struct CfgStatic : ZyCfgDefault { static constexpr bool DYNAMIC = false; };
 struct CfgStaticFence : ZyCfgDefault { static constexpr bool DYNAMIC = false; static constexpr int HANDOFF = 1; };
+struct CfgB8 : ZyCfgDefault { static constexpr int BUNDLE = 8; };
+struct CfgB8Fence : ZyCfgDefault { static constexpr int BUNDLE = 8; static constexpr int HANDOFF = 1; };
+struct CfgB16Fence : ZyCfgDefault { static constexpr int BUNDLE = 16; static constexpr int HANDOFF = 1; };
+struct CfgChunk64 : ZyCfgDefault { static constexpr int CHUNK = 64; };
+struct CfgChunk64B8Fence : ZyCfgDefault { static constexpr int CHUNK = 64; static constexpr int BUNDLE = 8; static constexpr int HANDOFF = 1; };
+struct CfgChunk64B16Fence : ZyCfgDefault { static constexpr int CHUNK = 64; static constexpr int BUNDLE = 16; static constexpr int HANDOFF = 1; };
+struct CfgChunk32B8Fence : ZyCfgDefault { static constexpr int CHUNK = 32; static constexpr int BUNDLE = 8; static constexpr int HANDOFF = 1; };
+struct CfgChunk64B8FenceStatic : CfgChunk64B8Fence { static constexpr bool DYNAMIC = false; };
+struct CfgSkelChunk64B8Fence : CfgChunk64B8Fence { static constexpr bool MATH = false; };
 struct CfgSkel : ZyCfgDefault { static constexpr bool MATH = false; };
 struct CfgSkelFence : ZyCfgDefault { static constexpr bool MATH = false; static constexpr int HANDOFF = 1; };
 
@@ -207,7 +216,17 @@ int main(int argc, char** argv) {
         dfft_plan_destroy(plan);
         CK(hipFree(out));
     }
-    for (unsigned lag : {16u, 8u, 32u, 4u}) {
+    // phase order (the library's 64-plane cache chunks inside one launch) with the hand-off cost paid once per bundle of units
+    run_variant<CfgChunk64B8Fence>(c, "chunk 64, bundle 8, plain + fences", 0, 1);
+    run_variant<CfgChunk64B16Fence>(c, "chunk 64, bundle 16, plain + fences", 0, 1);
+    run_variant<CfgChunk32B8Fence>(c, "chunk 32, bundle 8, plain + fences", 0, 1);
+    run_variant<CfgChunk64B8FenceStatic>(c, "chunk 64, bundle 8, fences, static", 0, 1);
+    run_variant<CfgSkelChunk64B8Fence>(c, "chunk 64, bundle 8, fences, no math", 0, 1);
+    run_variant<CfgChunk64>(c, "chunk 64, sc1 hand-off", 0, 1);
+    run_variant<CfgB8Fence>(c, "bundle 8, plain + fences", 32, 1);
+    run_variant<CfgB16Fence>(c, "bundle 16, plain + fences", 32, 1);
+    run_variant<CfgB8>(c, "bundle 8, sc1 hand-off", 32, 1);
+    for (unsigned lag : {64u, 16u, 8u, 32u, 4u}) {
         run_variant<ZyCfgDefault>(c, "stream sc1 hand-off", lag, 1);
         run_variant<CfgFence>(c, "stream plain + fences", lag, 1);
     }
