@@ -1,7 +1,7 @@
 // dfft_zy_stream.h -- EXPERIMENT (not linked into the library; tools/zy_stream.hip is the harness that verifies it against the
 // library kernels and times it).  First GPU run (profiles/r02/experiments/zy_stream_first_run.log): every variant bit-identical to
-// the library, none faster than its phase-separated chunks (1.52 ms at best against 1.37 ms); BUNDLE / CHUNK were added after
-// that run and have only been compiled.
+// the library; the interleaved orders are all slower than its phase-separated chunks (1.52 ms at best against 1.37 ms), the phase
+// order CHUNK = 64 with the sc1 hand-off is 2 % faster (1.337 ms: the launch boundaries), fences per bundle cost 0.15-0.2 ms.
 //
 // t0 (batched 2D YZ FFT of every owned plane; reference fftZY, /root/reference/3dmpifft_opt/include/fft_mpi_3d_api.cpp:466-522)
 // as ONE persistent launch in which the Z rows of plane p + LAG and the Y columns of plane p are in flight AT THE SAME TIME.
