@@ -268,6 +268,21 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["value"] / c["value"] > 100   # reported next to each other, not a target
 
 
+def test_pmc_summary_belongs_to_the_built_library(native_lib):
+    """profiles/hbm_traffic.json (the PMC traffic bench.py reports as roofline.traffic) carries the sha256 of the library it
+    was measured on.  A library built from the current sources with another hash makes bench.py report traffic = null with
+    the reason -- not an error, but worth knowing before a round ends: the test is skipped with that message then."""
+    import hashlib
+    import json
+    from distributedfft_amd import _lib
+    ent = json.loads((ROOT / "profiles" / "hbm_traffic.json").read_text())["512x512x512_fp64_P1"]
+    have = hashlib.sha256(Path(_lib.LIB_PATH).read_bytes()).hexdigest()
+    if ent["library_sha256"] != have:
+        pytest.skip(f"profiles/hbm_traffic.json was measured on library {ent['library_sha256'][:12]}, the tree builds "
+                    f"{have[:12]}: re-run tools/profile_bench.sh on the GPU box")
+    assert ent["fft_cols X(+transpose)"]["hbm_bytes_per_launch"] > 0
+
+
 def test_headline_kernels_do_not_spill():
     """The 512-point kernels of the benchmarked path (fp64, and fp32 on column pairs) must compile for gfx950 without
     scratch: a few extra live registers in the shared kernel template are enough to make the register-heavy variants spill,
