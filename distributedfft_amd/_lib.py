@@ -52,6 +52,7 @@ SIGNATURES = {
     "dfft_plan_buffer1": (_VP, [_VP]),
     "dfft_plan_result": (_VP, [_VP]),
     "dfft_plan_stream": (_VP, [_VP]),
+    "dfft_plan_workbuf": (_VP, [_VP, _LLP]),
     "dfft_execute": (C.c_int, [_VP, C.c_uint]),
     "dfft_plan_sync": (C.c_int, [_VP]),
     "dfft_plan_tune": (C.c_int, [_VP]),

@@ -112,14 +112,26 @@ int dfft_boot_init(void) {
         }
         sa.sin_port = htons((uint16_t)portno);
         bool bound = ::bind(ls, (sockaddr*)&sa, sizeof(sa)) == 0;
-        if (!bound && sa.sin_addr.s_addr != htonl(INADDR_LOOPBACK)) {
+        int  bind_errno = bound ? 0 : errno;
+        // Loopback is a substitute only when the named address does not exist on this host (EADDRNOTAVAIL: a container
+        // whose hostname resolves to an address of another namespace) -- any other failure (port in use, permission) is
+        // reported as it is: listening on loopback while the peers connect to the real address would hang the job.
+        if (!bound && bind_errno == EADDRNOTAVAIL && sa.sin_addr.s_addr != htonl(INADDR_LOOPBACK)) {
             sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
             bound = ::bind(ls, (sockaddr*)&sa, sizeof(sa)) == 0;
+            if (bound && getenv("DFFT_DEBUG"))
+                fprintf(stderr, "[dfft] rendezvous: %s is not a local address, listening on 127.0.0.1:%d (single-node jobs only)\n", addr, portno);
         }
         if (!bound || ::listen(ls, g.size) != 0) {
+            const int err = bound ? errno : bind_errno;
             ::close(ls);
-            return fail(DFFT_ECOMM, std::string("dfft_boot_init: bind/listen on port ") + std::to_string(portno) + ": " +
-                                        strerror(errno));
+            return fail(DFFT_ECOMM, std::string("dfft_boot_init: bind/listen on ") + addr + ":" + std::to_string(portno) + ": " +
+                                        strerror(err));
+        }
+        if (getenv("DFFT_DEBUG")) {
+            char txt[INET_ADDRSTRLEN] = "?";
+            inet_ntop(AF_INET, &sa.sin_addr, txt, sizeof(txt));
+            fprintf(stderr, "[dfft] rendezvous: rank 0 listening on %s:%d for %d ranks\n", txt, portno, g.size);
         }
         g.peers.assign(g.size, -1);
         for (int i = 1; i < g.size; ++i) {

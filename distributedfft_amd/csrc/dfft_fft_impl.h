@@ -21,8 +21,10 @@
 //   u     = DFT_R(u)
 //   dst   = (jq / Ns) * Ns * R + (jq mod Ns) + r*Ns        (scatter through LDS, skipped for the last stage)
 #pragma once
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "dfft_butterfly.h"
@@ -364,6 +366,19 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
 __device__ __forceinline__ long long block_term(const AxisMap& m, int ib) {
     if (m.sub > 1) return (long long)(ib / m.sub) * m.blk_stride + (long long)(ib % m.sub) * m.sub_stride;
     return (long long)ib * m.blk_stride;
+}
+// host twin of block_term + the largest element offset an axis map produces for n points (kernels that keep their
+// wave-uniform offsets in 32 bits are only chosen when this fits)
+inline long long axis_max_offset(const AxisMap& m, int n) {
+    long long mx = 0;
+    const int nb = m.blk > 0 ? (n + m.blk - 1) / m.blk : 1;
+    for (int ib = 0; ib < nb; ++ib) {
+        const long long bt = m.sub > 1 ? (long long)(ib / m.sub) * m.blk_stride + (long long)(ib % m.sub) * m.sub_stride : (long long)ib * m.blk_stride;
+        const int       cnt = (ib + 1) * m.blk <= n ? m.blk : n - ib * m.blk;
+        const long long o = bt + (long long)(cnt - 1) * m.stride;
+        if (o > mx) mx = o;
+    }
+    return mx;
 }
 // GENERAL = ragged last column tile and/or uneven last slab (slow-path address terms compiled in).
 // All offsets, strides and column counts are in units of one V (for cpair: 16 bytes = two fp32 columns).
@@ -810,12 +825,17 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     using KG = KernelGeom<V, P, CB, G, Tune>;
     auto kern = fft_tiles_kernel<V, P, CB, G, DIR, GENERAL, Tune>;
     // Per-device one-time set-up (function attributes are per device context): LDS opt-in and resident blocks per CU.
-    static int blocks_per_cu[64] = {0};
+    // (several device threads may launch the same instantiation at once: published with release / read with acquire, set up
+    // under a lock)
+    static std::atomic<int> blocks_per_cu[64];
+    static std::mutex       setup_mutex;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (blocks_per_cu[dev] == 0) {
+    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
+        if (blocks_per_cu[dev].load(std::memory_order_relaxed) == 0) {
         if (KG::LDS_BYTES > 64 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)KG::LDS_BYTES);
@@ -831,11 +851,12 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
             occ = 32 / waves;
             if (KG::LDS_BYTES > 0 && (int)(160 * 1024 / KG::LDS_BYTES) < occ) occ = (int)(160 * 1024 / KG::LDS_BYTES);
         }
-        blocks_per_cu[dev] = occ > 0 ? occ : 1;
+        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
+        }
     }
-    if (blocks_per_cu_out) *blocks_per_cu_out = blocks_per_cu[dev];
+    if (blocks_per_cu_out) *blocks_per_cu_out = blocks_per_cu[dev].load(std::memory_order_relaxed);
     const long long nblocks_needed = (L.ntiles + G - 1) / G;
-    int bpc = blocks_per_cu[dev];
+    int bpc = blocks_per_cu[dev].load(std::memory_order_relaxed);
     if (L.blocks_per_cu_limit > 0 && L.blocks_per_cu_limit < bpc) bpc = L.blocks_per_cu_limit;
     long long grid = (long long)device_info().cus * bpc;
     if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
@@ -857,15 +878,17 @@ template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(con
     using GV = typename VT::G;
     constexpr size_t LDS_BYTES = DualGeom<V, P, CB>::LDS_BYTES;
     auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT>;
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64];
+    static std::mutex        setup_mutex;
     int         dev = 0;
     hipError_t  e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * P::T);
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const long long tiles_per_a = L.ncols / (2 * CB), ntiles = L.na * tiles_per_a;
     if (ntiles <= 0) return hipSuccess;
@@ -887,15 +910,17 @@ template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool
     using GV = typename VT::G;
     constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB>::LDS_BYTES;
     auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT>;
-    static bool attr_set[64] = {false};
+    static std::atomic<bool> attr_set[64];
+    static std::mutex        setup_mutex;
     int         dev = 0;
     hipError_t  e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * PH::T);
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     const long long tiles_per_a = L.ncols / CB, ntiles = L.na * tiles_per_a;
     if (ntiles <= 0) return hipSuccess;
@@ -998,7 +1023,9 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
             const bool lines = L.imap.cstride == 1 && L.omap.cstride == 1 && L.itile.b_stride == 1 && L.otile.b_stride == 1;
             const bool even = L.ncols % CBF == 0 && L.imap.last_delta == 0 && L.omap.last_delta == 0;
             const bool sin = (L.hints & FFT_HINT_STREAM_IN) != 0, sout = (L.hints & FFT_HINT_STREAM_OUT) != 0;
-            if (!no_dif2 && lines && even && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0) {
+            // (the kernel keeps its per-point block offsets in 32 bits)
+            const bool fits32 = axis_max_offset(L.imap, P::N) < (1ll << 32) && axis_max_offset(L.omap, P::N) < (1ll << 32);
+            if (!no_dif2 && lines && even && fits32 && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0) {
                 if (L.dir > 0) {
                     if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true>(L, stream);
                     if (sin) return launch_dif2<V, PH, CBF, +1, true, false, true, true>(L, stream);

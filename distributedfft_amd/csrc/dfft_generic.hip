@@ -10,8 +10,10 @@
 //   * the radix sequence is a kernel argument, the butterflies are the same Butterfly<R> templates the tuned kernels use;
 //   * loads/stores walk the tile in the order that is contiguous in memory on that side (columns fastest, or the FFT
 //     index fastest for the transposed side), so both sides stay coalesced.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "dfft_butterfly.h"
 #include "dfft_kernels.h"
@@ -164,15 +166,17 @@ template <class V> hipError_t launch_generic_t(const FftLaunch& Lin, hipStream_t
     if (L.ntiles <= 0) return hipSuccess;
     if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     auto kern = L.dir > 0 ? fft_generic_kernel<V, +1> : fft_generic_kernel<V, -1>;
-    static bool attr_set[2][64] = {};
+    static std::atomic<bool> attr_set[2][64];
+    static std::mutex        setup_mutex;
     int         dev = 0;
     hipError_t  e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[L.dir > 0][dev]) {
+    if (!attr_set[L.dir > 0][dev].load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[L.dir > 0][dev] = true;
+        attr_set[L.dir > 0][dev].store(true, std::memory_order_release);
     }
     static thread_local int cached_dev = -1, cus = 256;
     if (cached_dev != dev) {

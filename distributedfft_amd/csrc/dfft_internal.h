@@ -33,6 +33,11 @@ struct Slab {
 };
 inline Slab make_slab(long long n, int P) { return Slab{n, P, (n + P - 1) / P}; }
 
+// Plan-owned slabs (hand-over buffer): hipMalloc, or one virtual range backed by physical chunks of a chosen size
+// (dfft_alloc.cpp; DFFT_W_ALLOC).  slab_free accepts pointers of either kind.
+hipError_t slab_alloc(void** p, size_t bytes);
+hipError_t slab_free(void* p);
+
 // Device twiddle table e^{-2 pi i k / n}, k < n, cached per (device, n, dtype).
 int get_twiddles(int n, int dtype, const void** table);
 

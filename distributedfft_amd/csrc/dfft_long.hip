@@ -100,7 +100,6 @@ struct LongTw {
 };
 std::mutex                                        g_mutex;
 std::map<std::tuple<int, long long, int>, LongTw> g_tw;       // (device, N, dtype)
-std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> g_scratch;  // (device, stream) -> buffer
 
 int long_twiddles(long long N, int dtype, LongTw* out) {
     int dev = 0;
@@ -191,22 +190,19 @@ bool long_split(long long n, int* n1, int* n2) {
     return true;
 }
 
+// Scratch for callers without a plan (the 1-D API): stream-ordered allocation from the device's memory pool, so that two
+// host threads on one stream never share or re-size a buffer and nothing outlives the call that needed it (the pool keeps
+// the pages for the next call).
 void* long_scratch(size_t bytes, hipStream_t stream) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mutex);
-    auto&                       e = g_scratch[std::make_pair(dev, stream)];
-    if (e.second < bytes) {
-        if (e.first) {
-            (void)hipStreamSynchronize(stream);  // work still using the old buffer
-            (void)hipFree(e.first);
-        }
-        e.first = nullptr;
-        e.second = 0;
-        if (hipMalloc(&e.first, bytes) != hipSuccess) return nullptr;
-        e.second = bytes;
+    void* p = nullptr;
+    if (hipMallocAsync(&p, bytes ? bytes : 16, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    return e.first;
+    return p;
+}
+void long_scratch_release(void* p, hipStream_t stream) {
+    if (p && hipFreeAsync(p, stream) != hipSuccess) (void)hipGetLastError();
 }
 
 int long_fft(const void* in, void* out, long long n, long long s, long long batch, int dtype, int dir, double scale, void* scratch,

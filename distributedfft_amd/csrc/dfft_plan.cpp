@@ -127,10 +127,15 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
                     const SlabLayout* lout = nullptr, long long rows_per_plane = 0, void* long_scratch_buf = nullptr) {
     if (n > 4096) {  // beyond the single-pass range: four-step decomposition (dfft_long.hip), plain contiguous rows only
         if (lin || lout) return fail(DFFT_EINVAL, "fft_rows: long axes use the natural layout");
+        if (rows <= 0) return DFFT_OK;
         const size_t off = (size_t)first_row * n * elem_bytes(dtype);
-        void*        scr = long_scratch_buf ? long_scratch_buf : (t_plan_scratch ? t_plan_scratch : long_scratch((size_t)rows * n * elem_bytes(dtype), s));
+        void*        scr = long_scratch_buf ? long_scratch_buf : t_plan_scratch;
+        const bool   own = !scr;
+        if (own) scr = long_scratch((size_t)rows * n * elem_bytes(dtype), s);
         if (!scr) return fail(DFFT_EHIP, "fft_rows: cannot allocate the scratch buffer of the four-step transform");
-        return long_fft((const char*)in + off, (char*)out + off, n, 1, rows, dtype, dir, scale, scr, s);
+        const int rc = long_fft((const char*)in + off, (char*)out + off, n, 1, rows, dtype, dir, scale, scr, s);
+        if (own) long_scratch_release(scr, s);
+        return rc;
     }
     const void* tw = nullptr;
     int         rc = get_twiddles(n, dtype, &tw);
@@ -460,7 +465,7 @@ static void w_tune_step(dfft_plan_s* p) {
     }
     if (more) {
         void* nw = nullptr;
-        if (hipMalloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype)) == hipSuccess) {  // earlier candidates stay allocated
+        if (slab_alloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype)) == hipSuccess) {  // earlier candidates stay allocated
             p->w_cand.push_back(nw);
             p->w_cur = have;
             p->w_runs = 0;
@@ -1078,16 +1083,18 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             p->wl.pitch = n2 + row_lines * line;
             p->wl.plane = n1 * p->wl.pitch + plane_lines * line;
             if (p->xs * p->wl.plane < (1ll << 31)) {
-                e = hipMalloc(&p->wbuf, (size_t)p->xs * p->wl.plane * elem_bytes(dtype));
-                if (e != hipSuccess) {
-                    dfft_plan_destroy(p);
-                    return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+                e = slab_alloc(&p->wbuf, (size_t)p->xs * p->wl.plane * elem_bytes(dtype));
+                if (e != hipSuccess) {  // an optimisation, not a requirement: run the natural layout in bufferDev1 instead
+                    (void)hipGetLastError();
+                    p->wbuf = nullptr;
+                    if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] no memory for the padded hand-over buffer (%s): natural layout\n", hipGetErrorString(e));
+                    e = hipSuccess;
                 }
                 if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] plan buffers: in %p out %p bufferDev1 %p work %p\n", in, out, p->buf1, p->wbuf);
                 // placement tuning: armed by dfft_plan_tune() (or from the first execute on with DFFT_TUNE=lazy)
                 const char* te = getenv("DFFT_TUNE");
-                p->w_cand.assign(1, p->wbuf);
-                if (direction == DFFT_FORWARD && te && !strcmp(te, "lazy") && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
+                if (p->wbuf) p->w_cand.assign(1, p->wbuf);
+                if (p->wbuf && direction == DFFT_FORWARD && te && !strcmp(te, "lazy") && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
                     hipEventCreate(&p->w_ev[1]) == hipSuccess)
                     p->w_tuning = true;
             }
@@ -1149,6 +1156,11 @@ int dfft_plan_set_scale(dfft_plan_t plan, double s) {
 void* dfft_plan_buffer1(dfft_plan_t plan) { return plan ? plan->buf1 : nullptr; }
 void* dfft_plan_result(dfft_plan_t plan) { return plan ? plan->buf2 : nullptr; }
 void* dfft_plan_stream(dfft_plan_t plan) { return plan ? (void*)plan->stream : nullptr; }
+void* dfft_plan_workbuf(dfft_plan_t plan, long long* bytes) {
+    if (!plan || !plan->wbuf) return nullptr;
+    if (bytes) *bytes = plan->xs * plan->wl.plane * (long long)elem_bytes(plan->dtype);
+    return plan->wbuf;
+}
 
 int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_execute: null plan");
@@ -1205,7 +1217,7 @@ int dfft_plan_tune(dfft_plan_t plan) {
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
-    for (void* w : plan->w_trash) (void)hipFree(w);
+    for (void* w : plan->w_trash) (void)slab_free(w);
     plan->w_trash.clear();
     if (plan->comm) return comm_check(plan->comm);
     return DFFT_OK;
@@ -1274,12 +1286,12 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
-    for (void* w : plan->w_trash) hipFree(w);
+    for (void* w : plan->w_trash) slab_free(w);
     if (!plan->w_cand.empty()) {
         for (void* w : plan->w_cand)
-            if (w) hipFree(w);
+            if (w) slab_free(w);
     } else if (plan->wbuf) {
-        hipFree(plan->wbuf);
+        slab_free(plan->wbuf);
     }
     for (auto& e : plan->w_ev)
         if (e) hipEventDestroy(e);
@@ -1289,7 +1301,8 @@ int dfft_plan_destroy(dfft_plan_t plan) {
 }
 
 int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype, int direction, void* stream) {
-    if (!in || !out || batch < 0) return fail(DFFT_EINVAL, "dfft_fft1d_rows: bad arguments");
+    if (!in || !out || batch < 0 || (dtype != DFFT_F64 && dtype != DFFT_F32) || (direction != DFFT_FORWARD && direction != DFFT_BACKWARD))
+        return fail(DFFT_EINVAL, "dfft_fft1d_rows: bad arguments");
     if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_rows: unsupported length");
     if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_rows: no HIP device visible (no CPU fallback)");
     return fft_rows(in, out, (int)n, batch, dtype, direction, (hipStream_t)stream);
@@ -1305,13 +1318,18 @@ int dfft_scale(void* data, long long count, int dtype, double s, void* stream) {
 
 int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
                     void* stream) {
-    if (!in || !out || batch < 0 || width < 1) return fail(DFFT_EINVAL, "dfft_fft1d_cols: bad arguments");
+    if (!in || !out || batch < 0 || width < 1 || (dtype != DFFT_F64 && dtype != DFFT_F32) ||
+        (direction != DFFT_FORWARD && direction != DFFT_BACKWARD))
+        return fail(DFFT_EINVAL, "dfft_fft1d_cols: bad arguments");
     if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_cols: unsupported length");
     if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_cols: no HIP device visible (no CPU fallback)");
     if (n > 4096) {
+        if (batch == 0) return DFFT_OK;
         void* scr = long_scratch((size_t)batch * n * width * elem_bytes(dtype), (hipStream_t)stream);
         if (!scr) return fail(DFFT_EHIP, "dfft_fft1d_cols: cannot allocate the scratch buffer of the four-step transform");
-        return long_fft(in, out, n, width, batch, dtype, direction, 1.0, scr, (hipStream_t)stream);
+        const int rc = long_fft(in, out, n, width, batch, dtype, direction, 1.0, scr, (hipStream_t)stream);
+        long_scratch_release(scr, (hipStream_t)stream);
+        return rc;
     }
     const void* tw = nullptr;
     int         rc = get_twiddles((int)n, dtype, &tw);

@@ -153,6 +153,9 @@ void* dfft_plan_buffer1(dfft_plan_t plan);
 /* the buffer holding the result after execute (bufferDev2 = out, or in when in-place). */
 void* dfft_plan_result(dfft_plan_t plan);
 void* dfft_plan_stream(dfft_plan_t plan); /* hipStream_t the plan enqueues on */
+/* Diagnostics: the plan's internal hand-over buffer between the passes (NULL when the plan has none) and its size in bytes.
+ * No counterpart in the reference (its intermediate is bufferDev1 itself, fft_mpi_3d_api.cpp:497). */
+void* dfft_plan_workbuf(dfft_plan_t plan, long long* bytes);
 /* fft_mpi_execute_dft_3d_c2c (fft_mpi_3d_api.cpp:181-214).  Collective over all devices of the communicator. */
 int dfft_execute(dfft_plan_t plan, unsigned exec_flags);
 /* Wait for the plan's stream. */
