@@ -320,9 +320,13 @@ def main():
         flags |= api.PLAN_OVERLAP  # exchange parts on a second stream behind the plane-chunked Z+Y passes
     plan = api.Plan(n0, n1, n2, a, b, comm, rank, P, api.FORWARD, flags)
     plan_setup = "dfft_plan_create"
+    tune_report = None
     if P == 1 and hasattr(plan, "tune"):
         plan.tune()  # plan-time measurement (FFTW_MEASURE-style, part of plan set-up, before any warm-up or timed step)
-        plan_setup += " + dfft_plan_tune (plan-time placement measurement, before warm-up; results bit-identical without it)"
+        plan_setup += (" + dfft_plan_tune (plan-time placement of the hand-over buffer: the X-pass kernel alone timed on a few "
+                       "candidate allocations, before warm-up; results bit-identical without it)")
+        if hasattr(plan, "tune_report"):
+            tune_report = plan.tune_report()
 
     # P > 1: the un-overlapped plan is both the diagnostic (full t2) and the referee -- the overlapped pipeline must
     # reproduce its result bit for bit on every rank, otherwise the timed loop falls back to it
@@ -563,6 +567,8 @@ def main():
             "reference_published": {"value": 644.112, "unit": "GFlops/s", "config": "512^3 fp64, 4 ranks, unnamed AMD GPUs "
                                     "(README.md:54 of the reference); comparable only at n_gpus=4"},
         }
+        if tune_report is not None:
+            result["plan_tune"] = tune_report  # X-pass kernel time per candidate hand-over buffer, the one kept, and its re-timing
         if P == 4 and args.size == (512, 512, 512) and args.precision == "fp64":
             result["vs_baseline"] = round(gflops / 644.112, 3)
         if P > 1:

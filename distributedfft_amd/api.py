@@ -218,11 +218,20 @@ class Plan:
         L.check(L.load().dfft_plan_sync(self.handle), "dfft_plan_sync")
 
     def tune(self) -> None:
-        """Plan-time measurement (dfft_plan_tune): a few complete forward transforms that settle where the plan's internal
-        hand-over buffer lives; overwrites the result buffer with valid results."""
+        """Plan-time measurement (dfft_plan_tune): times the X-pass kernel alone on a few candidate allocations of the plan's
+        internal hand-over buffer and keeps the fastest; the probe launches leave garbage in the result buffer."""
         import torch
         with torch.cuda.device(self.device):
             L.check(L.load().dfft_plan_tune(self.handle), "dfft_plan_tune")
+
+    def tune_report(self) -> dict:
+        """{'candidates_ms': [...], 'kept': i, 'kept_retimed_ms': t} of the last tune() (dfft_plan_tune_report)."""
+        ms = (C.c_double * 16)()
+        kept, fin = C.c_int(-1), C.c_double(0.0)
+        n = L.load().dfft_plan_tune_report(self.handle, 16, ms, C.byref(kept), C.byref(fin))
+        if n < 0:
+            L.check(n, "dfft_plan_tune_report")
+        return {"candidates_ms": [round(ms[i], 4) for i in range(min(n, 16))], "kept": kept.value, "kept_retimed_ms": round(fin.value, 4)}
 
     def set_scale(self, s: float) -> None:
         """Multiply the result of every later execute by s (folded into the X-pass kernel; 1.0 = the reference's

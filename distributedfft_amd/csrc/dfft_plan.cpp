@@ -217,22 +217,14 @@ struct dfft_plan_s {
     // contiguous rows and natural-layout columns need the four-step form then) and owns the scratch slab it needs
     bool                    long_axis = false;
     void*                   lbuf = nullptr;
-    // Placement tuning of the hand-over buffer (forward, single GPU).  Which physical pages a 2 GiB buffer lands on decides
-    // whether the X pass runs at 0.71 or 0.77 ms (same virtual addresses, same code: tools/placement_probe.py,
-    // profiles/r02/experiments/placement_probe.log), so the first executes of a plan try up to five allocations -- every one
-    // of them a complete, correct transform -- time their X pass with a pair of events and keep the fastest.  DFFT_TUNE=0: off.
-    std::vector<void*>      w_cand;          // allocations still alive while tuning (w_cand[w_cur] == wbuf)
-    std::vector<void*>      w_trash;         // losing candidates: freed at the next dfft_plan_sync / destroy (hipFree drains
-                                             // the device, which must not happen between two timed executes)
-    int                     w_cur = 0, w_runs = 0;   // current candidate, timed executes it has had
-    int                     w_skip = 8;              // executes of the current candidate still to be ignored: the first ~8
-                                                     // executes after an idle gap run the X pass 20 us faster and t0 40 us slower
-                                                     // (profiles/r02/experiments/drift_probe.log), and a fresh buffer's first
-                                                     // execute is not representative either
-    float                   w_t[3] = {0.f, 0.f, 0.f};  // the current candidate's timed X passes (the median is kept)
-    bool                    w_tuning = false, w_pending = false;
-    float                   w_ms[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
-    hipEvent_t              w_ev[2] = {nullptr, nullptr};
+    // Placement of the hand-over buffer (dfft_plan_tune).  The X pass runs 5-8 % faster when the buffer it reads and the
+    // buffer it writes lie in different regions of the device's physical memory (regions are 10+ GiB long, consecutive
+    // allocations usually share one; profiles/r03/README.md section 1, tools/xprobe.hip), so tuning times the X-pass kernel
+    // alone on a few candidate allocations -- spacer allocations in between move the candidates across region boundaries --
+    // and keeps the one on which it ran fastest.
+    std::vector<float>      w_ms;            // report: X-pass time of every candidate tried (w_ms[w_kept] is the kept one)
+    int                     w_kept = -1;
+    float                   w_final_ms = 0.f;  // the kept candidate re-timed after the others were freed
 };
 
 static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
@@ -419,65 +411,6 @@ struct StageClock {
         if (rc_) return rc_;  \
     } while (0)
 
-// Placement tuning (dfft_plan_s::w_cand): called at the start of a forward execute while tuning is on.
-static void w_tune_finish(dfft_plan_s* p) {
-    int best = 0;
-    for (int i = 1; i < (int)p->w_cand.size(); ++i)
-        if (p->w_ms[i] < p->w_ms[best]) best = i;
-    for (int i = 0; i < (int)p->w_cand.size(); ++i)
-        if (i != best && p->w_cand[i]) p->w_trash.push_back(p->w_cand[i]);
-    p->wbuf = p->w_cand[best];
-    p->w_cand.assign(1, p->wbuf);
-    p->w_cur = 0;
-    p->w_tuning = false;
-    if (getenv("DFFT_DEBUG"))
-        fprintf(stderr, "[dfft] hand-over buffer placement: X pass %.4f / %.4f / %.4f / %.4f / %.4f ms, kept candidate %d\n", p->w_ms[0],
-                p->w_ms[1] > 1e29f ? 0.f : p->w_ms[1], p->w_ms[2] > 1e29f ? 0.f : p->w_ms[2], p->w_ms[3] > 1e29f ? 0.f : p->w_ms[3],
-                p->w_ms[4] > 1e29f ? 0.f : p->w_ms[4], best);
-}
-static void w_tune_step(dfft_plan_s* p) {
-    if (p->w_pending) {  // the previous execute's X pass
-        float ms = 1e30f;
-        if (hipEventSynchronize(p->w_ev[1]) != hipSuccess || hipEventElapsedTime(&ms, p->w_ev[0], p->w_ev[1]) != hipSuccess) ms = 1e30f;
-        p->w_pending = false;
-        if (p->w_skip > 0) {
-            --p->w_skip;
-        } else {
-            p->w_t[p->w_runs < 3 ? p->w_runs : 2] = ms;
-            ++p->w_runs;
-        }
-    }
-    if (p->w_runs < 3) return;  // three timed executes per candidate, the median counts
-    {
-        float a = p->w_t[0], b = p->w_t[1], c = p->w_t[2];
-        p->w_ms[p->w_cur] = std::max(std::min(a, b), std::min(std::max(a, b), c));
-    }
-    // stop as soon as the candidates seen so far are in different modes (the fast one is kept); five draws at most
-    const int have = p->w_cur + 1;
-    bool      more = have < 5;
-    if (have >= 2) {
-        float lo = p->w_ms[0], hi = p->w_ms[0];
-        for (int i = 1; i < have; ++i) {
-            lo = std::min(lo, p->w_ms[i]);
-            hi = std::max(hi, p->w_ms[i]);
-        }
-        if (lo < 0.95f * hi) more = false;  // the two modes are 7-8 % apart (0.70-0.72 vs 0.76-0.78 ms at 512^3 fp64)
-    }
-    if (more) {
-        void* nw = nullptr;
-        if (slab_alloc(&nw, (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype)) == hipSuccess) {  // earlier candidates stay allocated
-            p->w_cand.push_back(nw);
-            p->w_cur = have;
-            p->w_runs = 0;
-            p->w_skip = 3;
-            p->wbuf = nw;
-            return;
-        }
-        (void)hipGetLastError();
-    }
-    w_tune_finish(p);
-}
-
 static int execute_forward(dfft_plan_s* p, bool sync) {
     const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
     const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
@@ -486,7 +419,6 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     // ---- t0: 2D YZ FFT of every owned plane ----
     // The Z and Y passes run chunk by chunk over groups of planes that fit the 256 MiB Infinity Cache, so the Y pass
     // reads what the Z pass just wrote from cache instead of HBM (measured 1.73 -> 1.31..1.44 ms at 512^3 fp64).
-    if (p->w_tuning) w_tune_step(p);
     const void*     zsrc = (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1;
     const bool      y_packs = fused && p->exch;
     // where the Z pass puts its rows for the Y pass: the padded work buffer when the plan has one (fused pipelines)
@@ -582,13 +514,7 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     DFFT_TRY(clk.end_stage());
     // ---- t3: X FFT (+ transpose to [yl][N2][N0]) ----
     if (fused) {
-        const bool tune = p->w_tuning && !p->exch && p->wbuf;
-        if (tune) DFFT_HIP_TRY(hipEventRecord(p->w_ev[0], p->stream));
         DFFT_TRY(launch_x(p, xsrc, p->buf2, false, 0, (!p->exch && p->wbuf) ? &zl : nullptr));
-        if (tune) {
-            DFFT_HIP_TRY(hipEventRecord(p->w_ev[1], p->stream));
-            p->w_pending = true;
-        }
     } else {
         hipError_t e = launch_transpose(p->dtype, p->buf1, p->buf2, n0, p->ys * n2, p->stream);
         if (e != hipSuccess) return fail(DFFT_EHIP, std::string("transpose: ") + hipGetErrorString(e));
@@ -1091,12 +1017,6 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                     e = hipSuccess;
                 }
                 if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] plan buffers: in %p out %p bufferDev1 %p work %p\n", in, out, p->buf1, p->wbuf);
-                // placement tuning: armed by dfft_plan_tune() (or from the first execute on with DFFT_TUNE=lazy)
-                const char* te = getenv("DFFT_TUNE");
-                if (p->wbuf) p->w_cand.assign(1, p->wbuf);
-                if (p->wbuf && direction == DFFT_FORWARD && te && !strcmp(te, "lazy") && hipEventCreate(&p->w_ev[0]) == hipSuccess &&
-                    hipEventCreate(&p->w_ev[1]) == hipSuccess)
-                    p->w_tuning = true;
             }
         }
     }
@@ -1190,35 +1110,136 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     return DFFT_OK;
 }
 
+// X-pass kernel of the plan alone on hand-over buffer `w` (forward: w -> result buffer, backward: source -> w): median of
+// five timed launches after two warm-up launches, in ms.  Results are garbage (w is not initialised); only the addresses matter.
+static int probe_x_pass(dfft_plan_s* p, void* w, float* ms_out) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    DFFT_HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return fail(DFFT_EHIP, "dfft_plan_tune: cannot create events");
+    }
+    float t[5];
+    int   rc = DFFT_OK;
+    for (int i = 0; i < 7 && rc == DFFT_OK; ++i) {
+        hipError_t e = hipEventRecord(e0, p->stream);
+        if (e == hipSuccess) {
+            if (p->direction == DFFT_FORWARD) rc = launch_x(p, w, p->buf2, false, 0, &p->wl);
+            else rc = launch_x(p, (p->flags & DFFT_PLAN_INPUT_FROM_IN) ? p->in : p->buf1, w, false, 0, &p->wl);
+        }
+        if (e == hipSuccess && rc == DFFT_OK) e = hipEventRecord(e1, p->stream);
+        if (e == hipSuccess && rc == DFFT_OK) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess && rc == DFFT_OK) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess && rc == DFFT_OK) rc = fail(DFFT_EHIP, std::string("dfft_plan_tune: ") + hipGetErrorString(e));
+        if (i >= 2) t[i - 2] = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    std::sort(t, t + 5);
+    *ms_out = t[2];
+    return DFFT_OK;
+}
+
 int dfft_plan_tune(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_tune: null plan");
     const char* te = getenv("DFFT_TUNE");
     if (te && *te == '0') return DFFT_OK;
-    // only single-GPU forward plans with a hand-over buffer have anything to measure
-    if (plan->direction != DFFT_FORWARD || plan->exch || !plan->wbuf || plan->w_cand.empty() || (plan->flags & DFFT_PLAN_NATURAL))
-        return DFFT_OK;
-    if (!plan->w_ev[0] && (hipEventCreate(&plan->w_ev[0]) != hipSuccess || hipEventCreate(&plan->w_ev[1]) != hipSuccess))
-        return fail(DFFT_EHIP, "dfft_plan_tune: cannot create events");
-    if (plan->w_cand.size() == 1 && !plan->w_tuning) {  // (re)start
-        for (float& m : plan->w_ms) m = 1e30f;
-        plan->w_cur = 0;
-        plan->w_runs = 0;
-        plan->w_skip = 8;
-        plan->w_pending = false;
-        plan->w_tuning = true;
+    // only fused single-GPU plans with a hand-over buffer have anything to place
+    if (plan->exch || !plan->wbuf || (plan->flags & (DFFT_PLAN_NATURAL | DFFT_PLAN_UNFUSED))) return DFFT_OK;
+    dfft_plan_s* p = plan;
+    DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
+    const size_t wbytes = (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype);
+    // Candidates: the current buffer, then fresh allocations with a spacer in front of each.  The regions that matter are tens
+    // of GiB long (one 128 GiB allocation is half and half; tools/xprobe.hip, profiles/r03/experiments/xprobe_*.log) and the
+    // driver hands out device memory top-down, so a spacer that stays allocated moves the next candidate that far on.  The
+    // spacers grow -- 8, 8, 16, 32, 64 GiB -- so that six candidates reach 130 GiB; bounded by DFFT_TUNE_TRIES (default 6) and
+    // by what is free (the transient footprint never exceeds 60 % of the free device memory).  DFFT_TUNE_SPACER_MB fixes the
+    // spacer size instead.
+    int         max_tries = 6;
+    const char* mt = getenv("DFFT_TUNE_TRIES");
+    if (mt && atoi(mt) > 0) max_tries = atoi(mt);
+    long long   fixed_spacer = -1;
+    const char* sm = getenv("DFFT_TUNE_SPACER_MB");
+    if (sm && atoll(sm) >= 0) fixed_spacer = atoll(sm) << 20;
+    auto spacer_for = [&](int k) -> size_t {  // spacer in front of candidate k (k >= 1)
+        if (fixed_spacer >= 0) return (size_t)fixed_spacer;
+        static const int gib[] = {8, 8, 16, 32, 64};
+        return (size_t)gib[std::min(k - 1, 4)] << 30;
+    };
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        free_b = 0;
     }
-    for (int i = 0; i < 40 && plan->w_tuning; ++i) {
-        const int rc = dfft_execute(plan, DFFT_EXEC_NO_TIMING);
-        if (rc) return rc;
+    const size_t budget = free_b / 10 * 6;
+    std::vector<void*> cand(1, p->wbuf), spacers;
+    p->w_ms.clear();
+    float ms = 0.f;
+    int   rc = probe_x_pass(p, p->wbuf, &ms);
+    if (rc) return rc;
+    p->w_ms.push_back(ms);
+    size_t used = 0;
+    while ((int)cand.size() < max_tries && used + spacer_for((int)cand.size()) + wbytes <= budget) {
+        const size_t spacer_bytes = spacer_for((int)cand.size());
+        float lo = p->w_ms[0], hi = p->w_ms[0];
+        for (float v : p->w_ms) {
+            lo = std::min(lo, v);
+            hi = std::max(hi, v);
+        }
+        if (cand.size() >= 2 && lo < 0.97f * hi) break;  // both placements seen (they are 5-8 % apart): keep the fast one
+        void *sp = nullptr, *nw = nullptr;
+        if (spacer_bytes > 0) {
+            if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            spacers.push_back(sp);
+        }
+        if (slab_alloc(&nw, wbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        used += spacer_bytes + wbytes;
+        cand.push_back(nw);
+        rc = probe_x_pass(p, nw, &ms);
+        if (rc) break;
+        p->w_ms.push_back(ms);
     }
-    return dfft_plan_sync(plan);  // also frees the candidates that lost
+    int best = 0;
+    for (int i = 1; i < (int)p->w_ms.size(); ++i)
+        if (p->w_ms[i] < 0.985f * p->w_ms[best]) best = i;  // a later candidate must be clearly faster to replace an earlier one
+    (void)hipStreamSynchronize(p->stream);
+    for (void* sp : spacers) (void)hipFree(sp);
+    for (int i = 0; i < (int)cand.size(); ++i)
+        if (i != best) (void)slab_free(cand[i]);
+    p->wbuf = cand[best];
+    p->w_kept = best;
+    if (rc) return rc;
+    // the kept buffer once more, now that its neighbours are gone (reported, not acted upon)
+    rc = probe_x_pass(p, p->wbuf, &p->w_final_ms);
+    if (getenv("DFFT_DEBUG")) {
+        fprintf(stderr, "[dfft] hand-over buffer placement: X pass");
+        for (float v : p->w_ms) fprintf(stderr, " %.4f", v);
+        fprintf(stderr, " ms, kept candidate %d (%.4f ms when re-timed)\n", best, p->w_final_ms);
+    }
+    return rc;
+}
+
+int dfft_plan_tune_report(dfft_plan_t plan, int max_n, double* ms, int* kept, double* final_ms) {
+    if (!plan || max_n < 0) return fail(DFFT_EINVAL, "dfft_plan_tune_report: bad arguments");
+    const int n = (int)plan->w_ms.size();
+    for (int i = 0; i < n && i < max_n; ++i)
+        if (ms) ms[i] = plan->w_ms[i];
+    if (kept) *kept = plan->w_kept;
+    if (final_ms) *final_ms = plan->w_final_ms;
+    return n;
 }
 
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
-    for (void* w : plan->w_trash) (void)slab_free(w);
-    plan->w_trash.clear();
     if (plan->comm) return comm_check(plan->comm);
     return DFFT_OK;
 }
@@ -1286,15 +1307,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->stream) hipStreamDestroy(plan->stream);
     if (plan->buf1) hipFree(plan->buf1);
     if (plan->rbuf) hipFree(plan->rbuf);
-    for (void* w : plan->w_trash) slab_free(w);
-    if (!plan->w_cand.empty()) {
-        for (void* w : plan->w_cand)
-            if (w) slab_free(w);
-    } else if (plan->wbuf) {
-        slab_free(plan->wbuf);
-    }
-    for (auto& e : plan->w_ev)
-        if (e) hipEventDestroy(e);
+    if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
     delete plan;
     return DFFT_OK;

@@ -160,15 +160,22 @@ void* dfft_plan_workbuf(dfft_plan_t plan, long long* bytes);
 int dfft_execute(dfft_plan_t plan, unsigned exec_flags);
 /* Wait for the plan's stream. */
 int dfft_plan_sync(dfft_plan_t plan);
-/* Optional plan-time measurement (the FFTW_MEASURE of this library; no counterpart in the reference): runs up to three dozen
- * complete forward transforms of the plan's current input -- the result buffer is overwritten with valid results -- and keeps,
- * of up to five allocations of the plan's internal hand-over buffer, the one on which the X pass ran fastest (which physical
- * pages a multi-GiB buffer lands on is worth 8 % of that pass).  Every candidate is timed in steady state: the first eight
- * executes after the idle gap of plan creation and the first three on a fresh buffer are ignored, the median of the next three
- * counts.  A no-op for plans that have no such buffer (P > 1, backward, un-fused, natural-order, cache-resident sizes) and
- * with DFFT_TUNE=0.  DFFT_TUNE=lazy does the same during a plan's first executes instead.  Results are bit-identical with and
- * without tuning. */
+/* Optional plan-time measurement (the FFTW_MEASURE of this library; no counterpart in the reference).  The X pass of a
+ * single-GPU plan reads the plan's internal hand-over buffer and writes the result buffer; it runs 5-8 % faster when the two
+ * lie in different regions of the device's physical memory (profiles/r03/README.md section 1), which consecutive allocations
+ * usually do not.  dfft_plan_tune times that ONE kernel -- seven launches of ~0.7 ms per candidate, no complete transforms --
+ * on the current buffer and on up to DFFT_TUNE_TRIES - 1 (default 5) fresh allocations with growing spacer allocations (8 ... 64
+ * GiB; the regions are tens of GiB long) in between, stops as soon as two candidates differ by 3 %, keeps the fastest and frees
+ * everything else (transient footprint: at most 60 % of the free device memory).  The probe launches overwrite the result buffer (forward plans) with garbage:
+ * call it before the first execute, not between an execute and the use of its result.  A no-op for plans without such a
+ * buffer (P > 1, un-fused, natural-order, cache-resident sizes) and with DFFT_TUNE=0.  Results of later executes are
+ * bit-identical with and without tuning.  The reference-named wrapper fft_mpi_plan_dft_c2c_3d, distFFTOpt, speed3d_c2c and
+ * bench.py all call it for out-of-place plans, so the drop-in CLI times the same configuration as the benchmark. */
 int dfft_plan_tune(dfft_plan_t plan);
+/* What the last dfft_plan_tune of this plan saw: ms[i] = X-pass kernel time on candidate i (at most max_n are written), *kept =
+ * index of the candidate the plan now uses (-1: never tuned), *final_ms = the kept candidate re-timed after the others were
+ * freed.  Returns the number of candidates tried.  Any output pointer may be NULL. */
+int dfft_plan_tune_report(dfft_plan_t plan, int max_n, double* ms, int* kept, double* final_ms);
 /* Multiply the result of every later execute by s (e.g. 1/N for a normalised transform: heFFTe's scale::full, the
  * reference's scale_element pass in 3dmpifft_roc, kernel_func.cpp:102-157).  Folded into the X-pass kernel's store, so it
  * costs no extra pass over the data.  s = 1 (the default) reproduces the reference's un-normalised transforms. */

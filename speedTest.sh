@@ -1,5 +1,6 @@
-#!/bin/bash
-# speedTest.sh <MPI-RANK> <X> <Y> <Z>   -- same CLI as /root/reference/3dmpifft_opt/speedTest.sh:6
+#!/bin/sh
+# speedTest.sh <MPI-RANK> <X> <Y> <Z>   -- same CLI (plain POSIX sh: the reference is started as `sh speedTest.sh ...`)
+#   as /root/reference/3dmpifft_opt/speedTest.sh:6
 #   (reference: mpirun -np $1 ... ./distFFTOpt $2 $3 $4 1)
 # <MPI-RANK> is the number of processes = number of GPUs (one process per GPU, RCCL over xGMI between them).  No MPI is
 # needed: the processes rendezvous over TCP on localhost (dfft_boot_*, include/dfft.h).  Set DFFT_MPIRUN="mpirun ..." to
@@ -19,14 +20,16 @@ if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ] && [ "$NGPU" -gt 0 ] && [ "${DFFT_EX
     # fewer GPUs than ranks, multi-process anyway: the hipIpc communicator lets several ranks share a GPU (round-robin)
     echo "speedTest.sh: $NGPU GPU(s) for $NP ranks -> $NP processes sharing them (DFFT_EXCHANGE=ipc)" >&2
     PORT=${DFFT_MASTER_PORT:-29533}
-    pids=()
-    for ((r = 0; r < NP; r++)); do
+    pids=""
+    r=0
+    while [ "$r" -lt "$NP" ]; do
         DFFT_RANK=$r DFFT_WORLD_SIZE=$NP DFFT_MASTER_ADDR=127.0.0.1 DFFT_MASTER_PORT=$PORT DFFT_LOCAL_DEVICE=$((r % NGPU)) \
             DFFT_VIRTUAL_DEVICES=1 "$BIN" $2 $3 $4 1 &
-        pids+=($!)
+        pids="$pids $!"
+        r=$((r + 1))
     done
     rc=0
-    for p in "${pids[@]}"; do wait "$p" || rc=$?; done
+    for p in $pids; do wait "$p" || rc=$?; done
     exit $rc
 fi
 if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ]; then
@@ -37,12 +40,14 @@ if [ "$NP" -gt 1 ] && [ "$NGPU" -lt "$NP" ]; then
 fi
 
 PORT=${DFFT_MASTER_PORT:-29533}
-pids=()
-for ((r = 0; r < NP; r++)); do
+pids=""
+r=0
+while [ "$r" -lt "$NP" ]; do
     DFFT_RANK=$r DFFT_WORLD_SIZE=$NP DFFT_MASTER_ADDR=127.0.0.1 DFFT_MASTER_PORT=$PORT DFFT_LOCAL_DEVICE=$r \
         "$BIN" $2 $3 $4 1 &
-    pids+=($!)
+    pids="$pids $!"
+    r=$((r + 1))
 done
 rc=0
-for p in "${pids[@]}"; do wait "$p" || rc=$?; done
+for p in $pids; do wait "$p" || rc=$?; done
 exit $rc

@@ -168,7 +168,7 @@ def test_speedtest_sh_multi_process_driver(gpu, tmp_path, ranks, overlap):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run(["bash", str(ROOT / "speedTest.sh"), str(ranks), "64", "32", "48"], capture_output=True, text=True,
+    r = subprocess.run(["sh", str(ROOT / "speedTest.sh"), str(ranks), "64", "32", "48"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     out = r.stdout

@@ -247,8 +247,9 @@ def test_execute_without_stage_events(gpu):
 
 def test_plan_tune_keeps_results_bit_identical(gpu):
     """dfft_plan_tune (plan-time placement measurement of the hand-over buffer): a plan that owns such a buffer -- planes a
-    multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- runs its candidates and produces bit for bit what
-    the un-tuned plan produces, before, during (every tuning execute is a complete transform) and after tuning."""
+    multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- probes its candidates with the X-pass kernel alone
+    (which leaves garbage in the result buffer) and afterwards produces bit for bit what the un-tuned plan produces, in both
+    directions, also after a second tuning round."""
     import torch
     from distributedfft_amd import api
     N = (512, 256, 256)
@@ -261,16 +262,32 @@ def test_plan_tune_keeps_results_bit_identical(gpu):
     p0 = api.Plan(*N, a, b0, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
     p0.execute(api.EXEC_NO_TIMING)
     p0.sync()
+    assert p0.tune_report()["kept"] == -1          # never tuned
     p1 = api.Plan(*N, a, b1, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
     p1.tune()
-    assert torch.equal(b0, b1)            # the last tuning execute left a complete result
-    b1.zero_()
+    rep = p1.tune_report()
+    assert 1 <= len(rep["candidates_ms"]) <= 6 and 0 <= rep["kept"] < len(rep["candidates_ms"]) and rep["kept_retimed_ms"] > 0
+    assert min(rep["candidates_ms"]) > 0
     p1.execute(api.EXEC_NO_TIMING)
     p1.sync()
     assert torch.equal(b0, b1)
-    p1.tune()                             # a second call restarts the measurement
+    p1.tune()                             # a second call measures again
+    b1.zero_()
     p1.execute()
     assert len(p1.stage_times()) == 4 and torch.equal(b0, b1)
+    # backward plans tune the same buffer from the other side (the inverse X pass writes it)
+    c0, c1 = torch.zeros_like(a), torch.zeros_like(a)
+    q0 = api.Plan(*N, b0, c0, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+    q1 = api.Plan(*N, b0, c1, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+    q1.tune()
+    assert q1.tune_report()["kept"] >= 0
+    for q in (q0, q1):
+        q.execute(api.EXEC_NO_TIMING)
+        q.sync()
+    assert torch.equal(c0, c1)
+    assert (c0 / n - a).abs().max().item() < 1e-12
+    q0.destroy()
+    q1.destroy()
     # spot check against the defining sum (the element-wise full-size checks live in test_gpu_fullsize.py)
     k = (3, 5, 7)
     idx = [torch.arange(m, device=gpu, dtype=torch.float64) for m in N]

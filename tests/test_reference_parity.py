@@ -105,7 +105,7 @@ def test_our_driver_surface_and_self_check(gpu, tmp_path, args, env):
 
 def test_speedtest_sh_cli(gpu, tmp_path):
     """sh speedTest.sh <ranks> X Y Z (speedTest.sh:6): with one GPU visible, ranks > 1 run as virtual devices."""
-    r = _run(["bash", ROOT / "speedTest.sh", 2, 32, 32, 32], cwd=tmp_path)
+    r = _run(["sh", ROOT / "speedTest.sh", 2, 32, 32, 32], cwd=tmp_path)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     s = _summary(r.stdout)
     assert s["size"] == "32x32x32" and float(s["err"]) < 1e-11
