@@ -64,6 +64,7 @@ SIGNATURES = {
     "dfft_fft1d_rows": (C.c_int, [_VP, _VP, _LL, _LL, C.c_int, C.c_int, _VP]),
     "dfft_fft1d_cols": (C.c_int, [_VP, _VP, _LL, _LL, _LL, C.c_int, C.c_int, _VP]),
     "dfft_scale": (C.c_int, [_VP, _LL, C.c_int, C.c_double, _VP]),
+    "dfft_trim": (C.c_int, []),
     "dfft_boot_init": (C.c_int, []),
     "dfft_boot_rank": (C.c_int, []),
     "dfft_boot_size": (C.c_int, []),

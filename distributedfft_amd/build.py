@@ -21,7 +21,7 @@ INCLUDE = ROOT / "include"
 ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
 HIPCC = str(ROCM / "bin" / "hipcc")
 ARCH = "gfx950"
-NUM_INST_GROUPS = 10  # keep in sync with csrc/dfft_plans.h
+NUM_INST_GROUPS = 12  # keep in sync with csrc/dfft_plans.h
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + str(INCLUDE), "-I" + str(CSRC),
           "-Wno-unused-result"]

@@ -108,42 +108,40 @@ template <> struct VecTraits<cpair> {
 // number of stored twiddle powers per butterfly
 constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 5 ? 3 : (R >= 3 ? 2 : (R >= 2 ? 1 : 0))); }
 
+// When T is a multiple of Ns all B butterflies of a thread's stage share one twiddle set ((j + q*T) mod Ns does not depend on
+// q), so only SLOTS registers are needed for that stage.  Counting this way would move N = 100, 1024 and 2048 from the LDS / L2
+// table to registers; measured (tools/kbench8.hip, round 1) that costs 3-6 % on the 1024/2048-point column kernels (register
+// pressure), so the sharing is switched on only for 4096 points, where 16 points x 256 threads then keep 12 twiddles in
+// registers instead of a 64 KiB LDS table that, next to the 72 KiB row tile, would leave one workgroup per CU.
+#ifndef DFFT_TW_EFFECTIVE
+#define DFFT_TW_EFFECTIVE 0
+#endif
+template <class P> constexpr bool tw_sharing() { return DFFT_TW_EFFECTIVE || P::N >= 4096; }
+
 template <class P, int S, bool TWPOW> struct StageInfo {
     using Prev = StageInfo<P, S - 1, TWPOW>;
     static constexpr int R = P::R[S];
     static constexpr int NS = Prev::NS * Prev::R;
     static constexpr int B = P::E / R;
     static constexpr int SLOTS = tw_slots(R, TWPOW);
+    static constexpr bool SHARED = tw_sharing<P>() && (P::T % NS == 0);  // one set for all B butterflies
+    static constexpr int QSTRIDE = SHARED ? 0 : SLOTS;                   // register distance between butterflies' sets
     static constexpr int TWOFF = Prev::TWOFF + Prev::TWCNT;
-    static constexpr int TWCNT = B * SLOTS;
+    static constexpr int TWCNT = SHARED ? SLOTS : B * SLOTS;
 };
 template <class P, bool TWPOW> struct StageInfo<P, 0, TWPOW> {
     static constexpr int R = P::R[0];
     static constexpr int NS = 1;
     static constexpr int B = P::E / R;
     static constexpr int SLOTS = 0;
+    static constexpr bool SHARED = false;
+    static constexpr int QSTRIDE = 0;
     static constexpr int TWOFF = 0;
     static constexpr int TWCNT = 0;
 };
 template <class P, bool TWPOW> struct TwTotal {
     using L = StageInfo<P, P::S - 1, TWPOW>;
     static constexpr int value = L::TWOFF + L::TWCNT;
-};
-// Distinct twiddle sets a thread really holds: when T is a multiple of Ns all B butterflies of a stage share one set
-// ((j + q*T) mod Ns does not depend on q), so only SLOTS registers are live for that stage.  Counting this way would
-// move N = 100, 1024 and 2048 from the LDS/L2 table to registers; measured (tools/kbench8.hip) that costs 3-6 % on the
-// 1024/2048-point column kernels (register pressure), so the switch is off and TWN decides.
-#ifndef DFFT_TW_EFFECTIVE
-#define DFFT_TW_EFFECTIVE 0
-#endif
-template <class P, int S, bool TWPOW> struct TwLive {
-    using SI = StageInfo<P, S, TWPOW>;
-    static constexpr bool SHARED = DFFT_TW_EFFECTIVE && (P::T % SI::NS == 0);
-    static constexpr int value = TwLive<P, S - 1, TWPOW>::value + (SHARED ? SI::SLOTS : SI::TWCNT);
-};
-template <class P, bool TWPOW> struct TwLive<P, 0, TWPOW> {
-    static constexpr bool SHARED = false;
-    static constexpr int value = 0;
 };
 
 template <int CB, bool PAD> __device__ __forceinline__ int lds_index(int idx, int c) {
@@ -172,14 +170,10 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
         using SI = StageInfo<P, S, TWPOW>;
         if constexpr (S > 0) {
 #pragma unroll
-            for (int q = 0; q < SI::B; ++q) {
+            for (int q = 0; q < (SI::SHARED ? 1 : SI::B); ++q) {
                 const int m = (j + q * P::T) % SI::NS;
 #pragma unroll
                 for (int s = 0; s < SI::SLOTS; ++s) {
-                    if (q > 0 && TwLive<P, S, TWPOW>::SHARED) {  // same value as butterfly 0: one register set
-                        twr[SI::TWOFF + q * SI::SLOTS + s] = twr[SI::TWOFF + s];
-                        continue;
-                    }
                     const int r = TWPOW ? (1 << s) : (s + 1);
                     W w = tw[(r * m) * (P::N / (SI::NS * SI::R))];
                     if (DIR < 0) w.y = -w.y;
@@ -225,7 +219,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
                     u[r] = cmul(u[r], w);
                 }
             } else if constexpr (TWPOW) {
-                const W* ws = twr + SI::TWOFF + q * SI::SLOTS;
+                const W* ws = twr + SI::TWOFF + q * SI::QSTRIDE;
                 W w[R > 1 ? R : 2];
                 w[1] = ws[0];
                 if constexpr (R >= 3) w[2] = ws[1];
@@ -238,7 +232,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], w[r]);
             } else {
 #pragma unroll
-                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[SI::TWOFF + q * (R - 1) + (r - 1)]);
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], twr[SI::TWOFF + q * SI::QSTRIDE + (r - 1)]);
             }
         }
         Butterfly<R, DIR, V>::run(u);
@@ -253,16 +247,35 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
 #endif
         if constexpr (PH == 1) {
             if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
+            // Padded rows (one element per 8): where the step between a thread's accesses is a multiple of 8 elements the
+            // padded index is affine in the access number -- written out that way so that the accesses become ONE address
+            // register plus immediate offsets (left to itself the compiler keeps an address register per access alive across
+            // the tile loop: 128 of them for 16 points x 4 stages, which made the 4096-point row kernel spill).
+            constexpr bool WAFF = PAD && (NS % 8 == 0 || (NS == 1 && R == 8));
+            constexpr bool RAFF = PAD && (T % 8 == 0);
 #pragma unroll
             for (int q = 0; q < B; ++q) {
                 const int jq = j + q * T;
                 const int base = (jq / NS) * (NS * R) + (jq % NS);
+                if constexpr (WAFF) {
+                    const int pb = lds_index<CB, PAD>(base, c);
+                    constexpr int step = (NS % 8 == 0 ? NS + NS / 8 : 1) * CB;
 #pragma unroll
-                for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
+                    for (int r = 0; r < R; ++r) lds[pb + r * step] = v[q + r * B];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
+                }
             }
             group_sync<WAVE_LOCAL>();
+            if constexpr (RAFF) {
+                const int pj = lds_index<CB, PAD>(j, c);
 #pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
+                for (int k = 0; k < E; ++k) v[k] = lds[pj + k * ((T + T / 8) * CB)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
+            }
         } else {
             static_assert(PH == 1 || (!PAD && !WAVE_LOCAL && CB % PH == 0), "two-phase exchange: block-wide column tiles");
             constexpr int CH = CB / PH;
@@ -310,7 +323,7 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     static_assert(!OSTAGE || P::N % LANES == 0, "the staged store of column pairs needs an even length");
     static constexpr int LDS_ELEMS = EX_ELEMS > OS_ELEMS ? EX_ELEMS : OS_ELEMS;
     static constexpr int TWN = TwTotal<P, Tune::TWPOW>::value;
-    static constexpr int TWLIVE = TwLive<P, P::S - 1, Tune::TWPOW>::value;
+    static constexpr int TWLIVE = TWN;  // distinct twiddle sets a thread holds
     // Twiddles live in VGPRs when the per-thread set is small (<= 16 distinct complex); otherwise in an LDS copy of the
     // table, unless that would push the block past the 160 KiB of a CU (then they are read through L1/L2).  (Budget raised
     // from 128 KiB in round 2: with the table in LDS the 1000-point column kernels spill 150 B instead of 550 B and run at
@@ -970,11 +983,44 @@ template <class V, class P> constexpr bool can_stage_store() {
 // Column launches describe the work as `na` slices of `ncols` columns; the tile geometry follows from the variant's CB.
 // Row launches (contiguous FFTs, one per tile) may use a plan of their own: the row kernel keeps no column tile in LDS, so
 // it can afford more points per thread than the column kernel of the same length (2048: 32 points, one wave per FFT).
+// Row FFTs that need a whole multi-wave workgroup (more than 2048 points: 4096, 2401, 3125): the register budget is set so
+// that as many workgroups are resident as the LDS allows (two of 72 KiB at 4096 points = 4 waves per SIMD = 128 VGPRs; without
+// the bound the compiler takes 150-206 registers and one workgroup per CU remains).  DFFT_ROWS_BIG_MINWAVES overrides (0 = off).
+#ifndef DFFT_ROWS_BIG_MINWAVES
+#define DFFT_ROWS_BIG_MINWAVES -1
+#endif
+template <class V, class P> constexpr int rows_big_min_waves() {
+    if (DFFT_ROWS_BIG_MINWAVES >= 0) return DFFT_ROWS_BIG_MINWAVES;
+    if (P::N <= 2048 || P::T < 256) return 0;
+    const int    waves_per_block = (P::T + 63) / 64;
+    const size_t lds = (size_t)(P::N + P::N / 8) * sizeof(V);
+    int          blocks = (int)(160 * 1024 / lds);
+    if (blocks > 2) blocks = 2;
+    const int w = blocks * waves_per_block / 4;  // waves per SIMD with `blocks` workgroups resident
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+template <int W> struct TuneRowsBig : TuneDefault {
+    static constexpr int  MIN_WAVES = W;
+    static constexpr bool PLAIN = true;  // rows are single-block maps: base + k * step, no per-point offset registers
+};
+template <int W> struct TuneRowsBigStreamIn : TuneStreamIn {
+    static constexpr int  MIN_WAVES = W;
+    static constexpr bool PLAIN = true;
+};
 template <class V, class P> hipError_t launch_rows(const FftLaunch& L, hipStream_t stream) {
     static_assert(VecTraits<V>::LANES == 1, "column pairs exist only for the column kernel");
     constexpr int GR = ConstMax1<256 / P::T>::value;  // ~256 threads per block
     if (L.ntiles <= 0) return hipSuccess;
     if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    constexpr int BW = rows_big_min_waves<V, P>();
+    if constexpr (BW > 0) {
+        if (L.hints & FFT_HINT_STREAM_IN) {
+            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneRowsBigStreamIn<BW>>(L, stream);
+            return launch_variant<V, P, 1, GR, -1, false, TuneRowsBigStreamIn<BW>>(L, stream);
+        }
+        if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneRowsBig<BW>>(L, stream);
+        return launch_variant<V, P, 1, GR, -1, false, TuneRowsBig<BW>>(L, stream);
+    }
     if (L.hints & FFT_HINT_STREAM_IN) {
         if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
         return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);

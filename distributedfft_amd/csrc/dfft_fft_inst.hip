@@ -27,6 +27,9 @@ template <int N> struct PlanRows : PlanFor<N> {};
 template <int N> struct PlanRows32 : PlanFor32<N> {};
 template <> struct PlanRows<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
 template <> struct PlanRows32<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
+// 3125 contiguous points: 625 threads x 5 points instead of 125 x 25 (two workgroups = 20 waves per CU instead of 4)
+template <> struct PlanRows<3125> { using type = Plan<3125, 5, 5, 5, 5, 5, 5>; };
+template <> struct PlanRows32<3125> { using type = Plan<3125, 5, 5, 5, 5, 5, 5>; };
 
 // Half plan for the DIF-split full-line column tiles (launch_plan): 2048-point columns run as two 1024-point transforms
 template <int N> struct PlanHalf { using type = void; };
@@ -100,6 +103,16 @@ template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
 #define DFFT_INST_IF_9(N) DFFT_DO_INST(N)
 #else
 #define DFFT_INST_IF_9(N)
+#endif
+#if DFFT_INST_GROUP == 10
+#define DFFT_INST_IF_10(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_10(N)
+#endif
+#if DFFT_INST_GROUP == 11
+#define DFFT_INST_IF_11(N) DFFT_DO_INST(N)
+#else
+#define DFFT_INST_IF_11(N)
 #endif
 
 DFFT_PLAN_TABLE(DFFT_INST_PLAN)

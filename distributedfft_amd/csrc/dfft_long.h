@@ -10,8 +10,10 @@ bool long_split(long long n, int* n1, int* n2);
 // times `scale`.  in == out is allowed.  `scratch` must hold batch * n * s elements and must not alias in / out.
 int long_fft(const void* in, void* out, long long n, long long s, long long batch, int dtype, int dir, double scale, void* scratch,
              hipStream_t stream);
-// scratch for callers without a plan (dfft_fft1d_rows / dfft_fft1d_cols): stream-ordered allocation, released in stream order
+// scratch for callers without a plan (dfft_fft1d_rows / dfft_fft1d_cols): a grow-only buffer per (device, stream), leased to one
+// host thread at a time -- long_scratch() takes the lease, long_scratch_release() returns it after the work has been enqueued
 void* long_scratch(size_t bytes, hipStream_t stream);
 void  long_scratch_release(void* p, hipStream_t stream);
+void  long_scratch_trim();  // frees every cached buffer that is not leased (dfft_trim)
 
 }  // namespace dfft

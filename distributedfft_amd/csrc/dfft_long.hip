@@ -14,6 +14,7 @@
 // grows with N.
 #include <mutex>
 #include <map>
+#include <memory>
 #include <cmath>
 #include <vector>
 
@@ -190,19 +191,70 @@ bool long_split(long long n, int* n1, int* n2) {
     return true;
 }
 
-// Scratch for callers without a plan (the 1-D API): stream-ordered allocation from the device's memory pool, so that two
-// host threads on one stream never share or re-size a buffer and nothing outlives the call that needed it (the pool keeps
-// the pages for the next call).
+// Scratch for callers without a plan (the 1-D API): one grow-only buffer per (device, stream).  The entry's lock is held from
+// long_scratch() until long_scratch_release(), i.e. across the caller's enqueue: a second host thread on the same stream waits
+// for the first one's kernels to be queued, and when it has to grow the buffer its hipStreamSynchronize covers them before the
+// old buffer is freed.  (hipMallocAsync / hipFreeAsync per call was tried first and gave wrong results on the NULL stream.)
+struct ScratchEntry {
+    std::mutex m;
+    void*      p = nullptr;
+    size_t     bytes = 0;
+};
+static std::map<std::pair<int, hipStream_t>, std::unique_ptr<ScratchEntry>> g_scratch;
+
 void* long_scratch(size_t bytes, hipStream_t stream) {
-    void* p = nullptr;
-    if (hipMallocAsync(&p, bytes ? bytes : 16, stream) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    ScratchEntry* e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mutex);
+        auto&                       slot = g_scratch[std::make_pair(dev, stream)];
+        if (!slot) slot.reset(new ScratchEntry);
+        e = slot.get();
     }
-    return p;
+    e->m.lock();
+    if (e->bytes < bytes) {
+        if (e->p) {
+            (void)hipStreamSynchronize(stream);  // work still using the old buffer
+            (void)hipFree(e->p);
+        }
+        e->p = nullptr;
+        e->bytes = 0;
+        if (hipMalloc(&e->p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            e->p = nullptr;
+            e->m.unlock();
+            return nullptr;
+        }
+        e->bytes = bytes;
+    }
+    return e->p;
 }
 void long_scratch_release(void* p, hipStream_t stream) {
-    if (p && hipFreeAsync(p, stream) != hipSuccess) (void)hipGetLastError();
+    if (!p) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    ScratchEntry* e = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mutex);
+        auto                        it = g_scratch.find(std::make_pair(dev, stream));
+        if (it != g_scratch.end()) e = it->second.get();
+    }
+    if (e && e->p == p) e->m.unlock();
+}
+void long_scratch_trim() {
+    std::lock_guard<std::mutex> lk(g_mutex);
+    for (auto& kv : g_scratch) {
+        ScratchEntry* e = kv.second.get();
+        if (!e->m.try_lock()) continue;  // in use right now
+        if (e->p) {
+            (void)hipStreamSynchronize(kv.first.second);
+            (void)hipFree(e->p);
+        }
+        e->p = nullptr;
+        e->bytes = 0;
+        e->m.unlock();
+    }
 }
 
 int long_fft(const void* in, void* out, long long n, long long s, long long batch, int dtype, int dir, double scale, void* scratch,

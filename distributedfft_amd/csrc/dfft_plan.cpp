@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "dfft_internal.h"
 #include "dfft_long.h"
@@ -1180,7 +1181,8 @@ int dfft_plan_tune(dfft_plan_t plan) {
     int   rc = probe_x_pass(p, p->wbuf, &ms);
     if (rc) return rc;
     p->w_ms.push_back(ms);
-    size_t used = 0;
+    std::vector<int> cand_of_ms(1, 0);
+    size_t           used = 0;
     while ((int)cand.size() < max_tries && used + spacer_for((int)cand.size()) + wbytes <= budget) {
         const size_t spacer_bytes = spacer_for((int)cand.size());
         float lo = p->w_ms[0], hi = p->w_ms[0];
@@ -1206,23 +1208,64 @@ int dfft_plan_tune(dfft_plan_t plan) {
         rc = probe_x_pass(p, nw, &ms);
         if (rc) break;
         p->w_ms.push_back(ms);
+        cand_of_ms.push_back((int)cand.size() - 1);
     }
-    int best = 0;
-    for (int i = 1; i < (int)p->w_ms.size(); ++i)
-        if (p->w_ms[i] < 0.985f * p->w_ms[best]) best = i;  // a later candidate must be clearly faster to replace an earlier one
+    auto spread_seen = [&]() {
+        float lo = p->w_ms[0], hi = p->w_ms[0];
+        for (float v : p->w_ms) {
+            lo = std::min(lo, v);
+            hi = std::max(hi, v);
+        }
+        return lo < 0.97f * hi;
+    };
     (void)hipStreamSynchronize(p->stream);
     for (void* sp : spacers) (void)hipFree(sp);
+    spacers.clear();
+    if (rc == DFFT_OK && !spread_seen() && cand.size() > 1 && !(mt && atoi(mt) > 0)) {
+        // Second phase: everything tried so far behaved alike.  The walk above only moves DOWN in address; memory above this
+        // process's first allocation may have become free meanwhile (a previous process's buffers are released lazily by the
+        // driver), and a fresh request is served from the highest free address.  Give the later candidates back, wait a
+        // moment, and try two more.
+        for (size_t i = 1; i < cand.size(); ++i) (void)slab_free(cand[i]);
+        cand.resize(1);
+        for (size_t i = 1; i < cand_of_ms.size(); ++i) cand_of_ms[i] = -1;
+        std::this_thread::sleep_for(std::chrono::milliseconds(60));
+        for (int extra = 0; extra < 2 && rc == DFFT_OK && !spread_seen(); ++extra) {
+            void *sp = nullptr, *nw = nullptr;
+            if (extra == 1 && used + ((size_t)24 << 30) <= budget && hipMalloc(&sp, (size_t)24 << 30) == hipSuccess) spacers.push_back(sp);
+            else (void)hipGetLastError();
+            if (slab_alloc(&nw, wbytes) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            cand.push_back(nw);
+            rc = probe_x_pass(p, nw, &ms);
+            if (rc) break;
+            // the report keeps one entry per buffer tried; entries of buffers already given back stay where they are
+            p->w_ms.push_back(ms);
+            cand_of_ms.push_back((int)cand.size() - 1);
+        }
+        for (void* sp : spacers) (void)hipFree(sp);
+    }
+    // w_ms[i] belongs to candidate cand_of_ms[i] (-1: given back before the end)
+    int best_ms = -1;
+    for (int i = 0; i < (int)p->w_ms.size(); ++i) {
+        if (cand_of_ms[i] < 0) continue;
+        if (best_ms < 0 || p->w_ms[i] < 0.985f * p->w_ms[best_ms]) best_ms = i;  // a later candidate must be clearly faster
+    }
+    const int best = cand_of_ms[best_ms];
+    (void)hipStreamSynchronize(p->stream);
     for (int i = 0; i < (int)cand.size(); ++i)
         if (i != best) (void)slab_free(cand[i]);
     p->wbuf = cand[best];
-    p->w_kept = best;
+    p->w_kept = best_ms;
     if (rc) return rc;
     // the kept buffer once more, now that its neighbours are gone (reported, not acted upon)
     rc = probe_x_pass(p, p->wbuf, &p->w_final_ms);
     if (getenv("DFFT_DEBUG")) {
         fprintf(stderr, "[dfft] hand-over buffer placement: X pass");
         for (float v : p->w_ms) fprintf(stderr, " %.4f", v);
-        fprintf(stderr, " ms, kept candidate %d (%.4f ms when re-timed)\n", best, p->w_final_ms);
+        fprintf(stderr, " ms, kept candidate %d (%.4f ms when re-timed)\n", p->w_kept, p->w_final_ms);
     }
     return rc;
 }
@@ -1319,6 +1362,11 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
     if (!dfft_length_supported(n)) return fail(DFFT_EUNSUPPORTED, "dfft_fft1d_rows: unsupported length");
     if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_rows: no HIP device visible (no CPU fallback)");
     return fft_rows(in, out, (int)n, batch, dtype, direction, (hipStream_t)stream);
+}
+
+int dfft_trim(void) {
+    long_scratch_trim();
+    return DFFT_OK;
 }
 
 int dfft_scale(void* data, long long count, int dtype, double s, void* stream) {

@@ -6,6 +6,8 @@
 // X(N, group, E, radices...) -- "group" only spreads the instantiations over translation units.
 // Powers of 3 and 5 (the reference's published component rows 243, 625, 2187, 3125: templateFFT/csv/batch_result1D.csv:5,6,14,16;
 // 2D 243^2, 729x243: batch_result2D.csv:32,33) run radix-3 / radix-5 stages with 9 (25 for 3125) points per thread.
+// 4096 and 2401 = 7^4 close the reference's single-pass range (templateFFT.cpp:3946: every power of two up to 4096 in one
+// upload); contiguous rows of 4096 and 3125 points use plans of their own (dfft_fft_inst.hip: 8 and 5 points per thread).
 #pragma once
 
 #define DFFT_PLAN_TABLE(X)        \
@@ -55,6 +57,8 @@
     X(729, 4, 9, 3, 3, 3, 3, 3, 3) \
     X(2187, 6, 9, 3, 3, 3, 3, 3, 3, 3) \
     X(625, 5, 5, 5, 5, 5, 5)      \
-    X(3125, 3, 25, 5, 5, 5, 5, 5)
+    X(3125, 3, 25, 5, 5, 5, 5, 5) \
+    X(4096, 10, 16, 8, 8, 8, 8)   \
+    X(2401, 11, 7, 7, 7, 7, 7)
 
-#define DFFT_NUM_INST_GROUPS 10
+#define DFFT_NUM_INST_GROUPS 12

@@ -196,6 +196,10 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
 int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
                     void* stream);
 
+/* Frees the scratch buffers the 1-D entry points cache per (device, stream) for lengths above 4096 (four-step transforms).
+ * Buffers in use by a call in progress are left alone.  No counterpart in the reference. */
+int dfft_trim(void);
+
 /* data[i] *= s for `count` complex elements on the device (the 1/N normalisation both transforms leave to the caller;
  * the reference's scale_element kernel, kernel_func.cpp:102-157, used only by 3dmpifft_roc). */
 int dfft_scale(void* data, long long count, int dtype, double s, void* stream);

@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 TOL = {"f64": 1e-11, "f32": 5e-4}
 # tuned plans (dfft_plans.h) ...
 TUNED = [2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 25, 32, 40, 48, 49, 64, 80, 96, 100, 125, 128, 160, 192, 200, 256, 320, 343,
-         384, 400, 512, 640, 768, 1000, 1024, 1280, 1536, 2048, 27, 81, 243, 625, 729, 2187, 3125]
+         384, 400, 512, 640, 768, 1000, 1024, 1280, 1536, 2048, 27, 81, 243, 625, 729, 2187, 3125, 2401, 4096]
 # ... and 7-smooth lengths served by the run-time-scheduled kernel (dfft_generic.hip): every radix mix, up to 4096
 GENERIC = [15, 18, 20, 21, 35, 36, 45, 50, 60, 63, 72, 90, 105, 120, 144, 210, 240, 250, 360, 500, 720,
-           800, 2000, 2401, 3072, 4000, 4096]
+           800, 2000, 3072, 4000, 3600]
 LENGTHS = TUNED + GENERIC
 
 
@@ -134,6 +134,8 @@ SHAPES = [
     # lengths without a tuned plan (run-time-scheduled kernel) on every axis, with pack / transposed store / uneven slabs
     ((20, 36, 40), 1), ((20, 36, 40), 4), ((45, 50, 18), 4), ((1000, 6, 8), 2), ((8, 640, 12), 2), ((4096, 2, 8), 1),
     ((16, 24, 1536), 2), ((60, 64, 20), 8),
+    # the top of the single-pass range on every axis: 4096 (16 points per thread, 2-column tiles) and 2401 = 7^4
+    ((4, 4096, 8), 2), ((2, 8, 4096), 1), ((2401, 3, 4), 1), ((4, 6, 2401), 2),
 ]
 
 
@@ -266,7 +268,7 @@ def test_plan_tune_keeps_results_bit_identical(gpu):
     p1 = api.Plan(*N, a, b1, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
     p1.tune()
     rep = p1.tune_report()
-    assert 1 <= len(rep["candidates_ms"]) <= 6 and 0 <= rep["kept"] < len(rep["candidates_ms"]) and rep["kept_retimed_ms"] > 0
+    assert 1 <= len(rep["candidates_ms"]) <= 8 and 0 <= rep["kept"] < len(rep["candidates_ms"]) and rep["kept_retimed_ms"] > 0
     assert min(rep["candidates_ms"]) > 0
     p1.execute(api.EXEC_NO_TIMING)
     p1.sync()

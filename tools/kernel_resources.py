@@ -32,7 +32,7 @@ def kernel_table(group: int):
     for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel|21fft_dif2_tiles_kernel)\w+): ", asm, re.M):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
-        mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)EEEv", name)
+        mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)(?:ILi\d+EE)?EEEv", name)
         md = re.match(r"_ZN4dfft21fft_dual_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])EEEv", name)
         if mm:
             ty = TYPES.get(mm.group(1), mm.group(1))
