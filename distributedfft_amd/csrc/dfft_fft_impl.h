@@ -983,44 +983,15 @@ template <class V, class P> constexpr bool can_stage_store() {
 // Column launches describe the work as `na` slices of `ncols` columns; the tile geometry follows from the variant's CB.
 // Row launches (contiguous FFTs, one per tile) may use a plan of their own: the row kernel keeps no column tile in LDS, so
 // it can afford more points per thread than the column kernel of the same length (2048: 32 points, one wave per FFT).
-// Row FFTs that need a whole multi-wave workgroup (more than 2048 points: 4096, 2401, 3125): the register budget is set so
-// that as many workgroups are resident as the LDS allows (two of 72 KiB at 4096 points = 4 waves per SIMD = 128 VGPRs; without
-// the bound the compiler takes 150-206 registers and one workgroup per CU remains).  DFFT_ROWS_BIG_MINWAVES overrides (0 = off).
-#ifndef DFFT_ROWS_BIG_MINWAVES
-#define DFFT_ROWS_BIG_MINWAVES -1
-#endif
-template <class V, class P> constexpr int rows_big_min_waves() {
-    if (DFFT_ROWS_BIG_MINWAVES >= 0) return DFFT_ROWS_BIG_MINWAVES;
-    if (P::N <= 2048 || P::T < 256) return 0;
-    const int    waves_per_block = (P::T + 63) / 64;
-    const size_t lds = (size_t)(P::N + P::N / 8) * sizeof(V);
-    int          blocks = (int)(160 * 1024 / lds);
-    if (blocks > 2) blocks = 2;
-    const int w = blocks * waves_per_block / 4;  // waves per SIMD with `blocks` workgroups resident
-    return w < 1 ? 1 : (w > 8 ? 8 : w);
-}
-template <int W> struct TuneRowsBig : TuneDefault {
-    static constexpr int  MIN_WAVES = W;
-    static constexpr bool PLAIN = true;  // rows are single-block maps: base + k * step, no per-point offset registers
-};
-template <int W> struct TuneRowsBigStreamIn : TuneStreamIn {
-    static constexpr int  MIN_WAVES = W;
-    static constexpr bool PLAIN = true;
-};
+// (Row FFTs that need a whole multi-wave workgroup -- 4096, 2401, 3125 points -- were also tried with the register budget
+// bounded so that two workgroups are resident per CU: every such build spills (100-430 B) and runs at 0.5-0.95 of the
+// unbounded kernels' rate -- 4096: 8979 vs 9196 GFlop/s, 2401: 4324 vs 7095, 3125: 3242 vs 7602; profiles/r03/experiments/
+// rows_ab_*.log -- so they keep the default: one fat workgroup per CU, no scratch.)
 template <class V, class P> hipError_t launch_rows(const FftLaunch& L, hipStream_t stream) {
     static_assert(VecTraits<V>::LANES == 1, "column pairs exist only for the column kernel");
     constexpr int GR = ConstMax1<256 / P::T>::value;  // ~256 threads per block
     if (L.ntiles <= 0) return hipSuccess;
     if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
-    constexpr int BW = rows_big_min_waves<V, P>();
-    if constexpr (BW > 0) {
-        if (L.hints & FFT_HINT_STREAM_IN) {
-            if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneRowsBigStreamIn<BW>>(L, stream);
-            return launch_variant<V, P, 1, GR, -1, false, TuneRowsBigStreamIn<BW>>(L, stream);
-        }
-        if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneRowsBig<BW>>(L, stream);
-        return launch_variant<V, P, 1, GR, -1, false, TuneRowsBig<BW>>(L, stream);
-    }
     if (L.hints & FFT_HINT_STREAM_IN) {
         if (L.dir > 0) return launch_variant<V, P, 1, GR, +1, false, TuneStreamIn>(L, stream);
         return launch_variant<V, P, 1, GR, -1, false, TuneStreamIn>(L, stream);
