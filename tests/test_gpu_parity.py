@@ -247,6 +247,45 @@ def test_execute_without_stage_events(gpu):
     plan.destroy()
 
 
+def test_untimed_executes_back_to_back_are_bit_identical(gpu):
+    """Un-timed executes (DFFT_EXEC_NO_TIMING, what a production loop and bench.py's timed steps use) queued back to back on
+    the plan's stream: same results as the event-timed executes, input changes are seen, a changed scale factor takes effect,
+    both directions, a chunked and a cache-resident size."""
+    import torch
+    from distributedfft_amd import api
+    for N in ((64, 32, 48), (512, 256, 256)):
+        n = N[0] * N[1] * N[2]
+        g = torch.Generator(device=gpu)
+        g.manual_seed(11)
+        a = torch.complex(torch.rand(n, generator=g, device=gpu, dtype=torch.float64) - 0.5,
+                          torch.rand(n, generator=g, device=gpu, dtype=torch.float64) - 0.5)
+        b, b_ref, c = torch.zeros_like(a), torch.zeros_like(a), torch.zeros_like(a)
+        ref = api.Plan(*N, a, b_ref, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+        p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+        q = api.Plan(*N, b, c, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+        for it in range(4):
+            a.mul_(1.0 + 0.125 * it)       # new input every round
+            torch.cuda.synchronize()
+            ref.execute()
+            ref.sync()
+            for _ in range(3):
+                p.execute(api.EXEC_NO_TIMING)
+            p.sync()
+            assert torch.equal(b, b_ref), (N, it)
+            q.execute(api.EXEC_NO_TIMING)
+            q.sync()
+            assert (c / n - a).abs().max().item() < 1e-12
+        p.set_scale(0.5)
+        ref.set_scale(0.5)
+        ref.execute()
+        ref.sync()
+        p.execute(api.EXEC_NO_TIMING)
+        p.sync()
+        assert torch.equal(b, b_ref)
+        for pl in (ref, p, q):
+            pl.destroy()
+
+
 def test_plan_tune_keeps_results_bit_identical(gpu):
     """dfft_plan_tune (plan-time placement measurement of the hand-over buffer): a plan that owns such a buffer -- planes a
     multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- probes its candidates with the X-pass kernel alone
