@@ -473,7 +473,19 @@ void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, st
     }
 }
 
+// DFFT_EXCHANGE_NOOP=1 (measurement hook, tools/local_by_P.py): the exchange moves nothing and synchronises nobody, so that ONE
+// rank of a P-rank plan can be executed alone and its local stages (t0, t3) timed with the real P > 1 address maps.  The
+// results are garbage by construction.
+static bool exchange_noop() {
+    static const bool on = [] {
+        const char* e = getenv("DFFT_EXCHANGE_NOOP");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
 int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
+    if (exchange_noop()) return DFFT_OK;
     const Round r = whole_round(x);
     if (c->kind == 3) return exchange_ipc_async(c, x, r, stream);
     if (c->kind != 1) return exchange_local(c, x, r, stream);
@@ -481,6 +493,7 @@ int comm_exchange(dfft_comm_t c, const ExchangeDesc& x, hipStream_t stream) {
 }
 
 int comm_exchange_part(dfft_comm_t c, const ExchangeDesc& x, int k, long long cp, hipStream_t stream, int ycut) {
+    if (exchange_noop()) return DFFT_OK;
     if ((int)x.xsize.size() != x.P || (int)x.ysize.size() != x.P || cp < 1 || k < 0 || ycut >= x.ycuts)
         return fail(DFFT_EINVAL, "comm_exchange_part: descriptor has no plane geometry");
     const Round r = part_round(x, k, cp, ycut);

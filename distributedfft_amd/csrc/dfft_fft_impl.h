@@ -50,6 +50,16 @@ struct TuneDefault {
     static constexpr int CB_OVERRIDE = 0;  // columns per tile (0 = cols_per_tile())
     static constexpr bool PLAIN = false;   // single-block address maps: offsets = base + k*step (no per-point VGPRs)
     static constexpr bool PREFETCH = false; // issue the next tile's loads before processing the current one (+E complex VGPRs)
+    static constexpr bool ROT = false;      // row rotation of an exchange-buffer side compiled in (RotMap, dfft_kernels.h)
+    static constexpr int ROT_IN = 0, ROT_OUT = 0;  // RotMap mode of the input / output side (compile time: 0, 1 or 2)
+};
+// any policy + the row rotation of the exchange buffers on one side (RIN / ROUT = RotMap::in_mode / out_mode).  The mode is a
+// compile-time property on purpose: a first version tested rm.in_mode / rm.out_mode at run time inside the unrolled load / store
+// loops, and that build stored the results of points 5 and 7 of the 8-point-per-thread Y pass wrongly (GPU parity test
+// test_rotated_exchange_rows_vs_oracle, 64^3 on 2 devices); with the mode in the type all 24 cases are bit-identical.
+template <class Base, int RIN, int ROUT> struct WithRot : Base {
+    static constexpr bool ROT = true;
+    static constexpr int  ROT_IN = RIN, ROT_OUT = ROUT;
 };
 
 // Column kernel whose store side is the transposed one ([..][z][kx], kx fastest: the forward X pass).  Measured on
@@ -66,6 +76,8 @@ struct TuneTransposedStore {
     static constexpr int CB_OVERRIDE = 0;
     static constexpr bool PLAIN = false;
     static constexpr bool PREFETCH = true;
+    static constexpr bool ROT = false;
+    static constexpr int ROT_IN = 0, ROT_OUT = 0;
 };
 
 // Column kernel default: the next tile's loads are issued before the current tile's exchanges (0.945 -> 0.869 ms on the
@@ -400,7 +412,7 @@ __global__ void __attribute__((amdgpu_flat_work_group_size(1, KernelGeom<V, P, C
                                amdgpu_waves_per_eu(Tune::MIN_WAVES > 0 ? Tune::MIN_WAVES : 1)))
 fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out,
                  const typename VecTraits<V>::W* __restrict__ tw, AxisMap imap, AxisMap omap, TileMap itile, TileMap otile,
-                 unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first, double scale) {
+                 unsigned ntiles, unsigned tiles_per_a, int ncols, unsigned a_first, double scale, RotMap rm) {
     using KG = KernelGeom<V, P, CB, G, Tune>;
     using VT = VecTraits<V>;
     using W = typename VT::W;
@@ -435,7 +447,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 
     // Per-thread element offsets of its E points relative to the tile base (constant over tiles).
     // PLAIN maps (one block, no uneven slab): offset = base + k * step with a wave-uniform step, no per-point VGPRs.
-    constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE;
+    constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE && !Tune::ROT;
     constexpr int NREL = PLAIN ? 1 : E;
     constexpr int ON = N / LANES;  // staged store: memory elements (GV) per scalar column
     // staged store with ON a multiple of the group size (every power-of-two plan): the element a thread stores at step k is
@@ -498,6 +510,8 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         }
         return lin;
     };
+    // point rotation: plane of point k of this thread = j + T * k, so its rotation is (rot_j + k * rot_t) mod row length
+    const int rot_j = Tune::ROT ? (rm.rot * j) & rm.mask : 0, rot_t = Tune::ROT ? (rm.rot * T) & rm.mask : 0;
     // loads the E points of the tile group starting at t into dst (zeros for tiles / columns past the end)
     auto load_tile = [&](unsigned t, V* dst) {
         const unsigned tile = map_tile(t + g);
@@ -506,12 +520,17 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         const unsigned b = tile - al * tiles_per_a;
         const unsigned a = al + a_first;
         if (GENERAL) ok = ok && ((int)(b * CB) + c < ncols);
-        const GV* ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride;
+        // rotated rows (exchange buffers): the tile's first column moves inside its row -- by the tile's plane (mode 1) or,
+        // per point, by the plane the point belongs to (mode 2); the sides this applies to have unit column stride
+        int cb0 = (int)(b * CB);
+        if constexpr (Tune::ROT_IN == 1) cb0 = (cb0 + rm.rot * (int)(a + (unsigned)rm.a0)) & rm.mask;
+        const GV* ip = in + (long long)a * itile.a_stride + (long long)cb0 * itile.b_stride;
         if (ok) {
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
+                if constexpr (Tune::ROT_IN == 2) off += (long long)(((cb0 + rot_j + k * rot_t) & rm.mask) - cb0);
                 dst[k] = VT::from_g(gload<Tune::NTL>(ip + off));
             }
         } else {
@@ -533,7 +552,9 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         const unsigned b = tile - al * tiles_per_a;
         const unsigned a = al + a_first;  // launches over a sub-range of `a` (plane chunks) keep global addressing
         if (GENERAL) valid = valid && ((int)(b * CB) + c < ncols);
-        GV* op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride;
+        int ob0 = (int)(b * CB);
+        if constexpr (Tune::ROT_OUT == 1) ob0 = (ob0 + rm.rot * (int)(a + (unsigned)rm.a0)) & rm.mask;
+        GV* op = out + (long long)a * otile.a_stride + (long long)ob0 * otile.b_stride;
 
         if constexpr (PREFETCH) {
             // issue the next tile's HBM loads now; they complete underneath this tile's exchanges and stores
@@ -598,6 +619,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
+                if constexpr (Tune::ROT_OUT == 2) off += (long long)(((ob0 + rot_j + k * rot_t) & rm.mask) - ob0);
                 gstore<Tune::NTS>(op + off, VT::to_g(cscale(v[k], sc)));
             }
         }
@@ -624,11 +646,11 @@ template <class V, class P, int CB> struct DualGeom {
     static constexpr size_t LDS_BYTES = TW_BYTES + (size_t)ROW * CB * sizeof(V);
     static_assert(LDS_BYTES <= 160 * 1024, "dual tiles: tile + twiddle table must fit the CU's LDS");
 };
-template <class V, class P, int CB, int DIR, bool NT>
+template <class V, class P, int CB, int DIR, bool NT, bool ROT = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * P::T), amdgpu_waves_per_eu(1)))
 fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
-                      double scale) {
+                      double scale, RotMap rm) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
@@ -641,10 +663,10 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     // multiples of 8 (8, 16) 4.5.
     using DG = DualGeom<V, P, CB>;
     constexpr bool PADROW = DG::PADROW;
-    constexpr int  ROW = DG::ROW, ROT = LANES;
+    constexpr int  ROW = DG::ROW, IMGROT = LANES;
     auto img_at = [](int col, int e) -> int {  // element e of scalar column col, in units of W
         if constexpr (PADROW) return col * ROW + e;
-        else return col * N + ((e + ROT * col) & (N - 1));
+        else return col * N + ((e + IMGROT * col) & (N - 1));
     };
     constexpr size_t TW_BYTES = ((size_t)N * sizeof(W) + 15) / 16 * 16;
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
@@ -677,6 +699,8 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     // pairing (3.3 vs 3.6 TB/s: the XCD-aware tile order of fft_tiles_kernel already brings the half lines together in one L2
     // and that kernel keeps two workgroups' worth of loads in flight), so launch_plan pairs tiles for the transposing store only.
     const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
+    // rotated rows of the receive buffer (RotMap mode 2): the pair of tiles of plane j + T k starts rot * plane further on in its row
+    const int rot_j = ROT ? (rm.rot * j) & rm.mask : 0, rot_t = ROT ? (rm.rot * T) & rm.mask : 0;
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         const GV*      ip = in + (long long)a * itile.a_stride + (long long)b * (2 * CB) * itile.b_stride + ithr;
@@ -684,8 +708,13 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
         V v0[E], v1[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            v0[k] = VT::from_g(gload<NT>(ip + iuni[k]));
-            v1[k] = VT::from_g(gload<NT>(ip + iuni[k] + (long long)CB * imap.cstride));
+            long long off = iuni[k];
+            if constexpr (ROT) {
+                const int cb0 = (int)(b * (2 * CB));
+                off += (long long)(((cb0 + rot_j + k * rot_t) & rm.mask) - cb0);
+            }
+            v0[k] = VT::from_g(gload<NT>(ip + off));
+            v1[k] = VT::from_g(gload<NT>(ip + off + (long long)CB * imap.cstride));
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -734,11 +763,11 @@ template <class V, class PH, int CB> struct Dif2Geom {
 };
 // BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
 // which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT>
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, bool ROT = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(1)))
 fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
-                      double scale) {
+                      double scale, RotMap rm) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
@@ -785,8 +814,15 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
-        const GV*      ip = in + (long long)a * itile.a_stride + (long long)b * CB * itile.b_stride + ithr;
-        GV*            op = out + (long long)a * otile.a_stride + (long long)b * CB * otile.b_stride + othr;
+        // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
+        int cbi = (int)(b * CB), cbo = (int)(b * CB);
+        if constexpr (ROT) {
+            const int r = rm.rot * (int)(a + (unsigned)rm.a0);
+            if (rm.in_mode == 1) cbi = (cbi + r) & rm.mask;
+            if (rm.out_mode == 1) cbo = (cbo + r) & rm.mask;
+        }
+        const GV*      ip = in + (long long)a * itile.a_stride + (long long)cbi * itile.b_stride + ithr;
+        GV*            op = out + (long long)a * otile.a_stride + (long long)cbo * otile.b_stride + othr;
         V v0[E], v1[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) {
@@ -879,18 +915,18 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     using GV = typename VecTraits<V>::G;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KG::THREADS), KG::LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out,
                        (const typename VecTraits<V>::W*)L.tw, L.imap, L.omap, L.itile, L.otile, (unsigned)L.ntiles,
-                       (unsigned)L.tiles_per_a, L.ncols, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
+                       (unsigned)L.tiles_per_a, L.ncols, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)KG::LDS_BYTES, KG::THREADS);
     return hipSuccess;
 }
 
-template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(const FftLaunch& L, hipStream_t stream) {
+template <class V, class P, int CB, int DIR, bool NT, bool ROT = false> hipError_t launch_dual(const FftLaunch& L, hipStream_t stream) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
     constexpr size_t LDS_BYTES = DualGeom<V, P, CB>::LDS_BYTES;
-    auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT>;
+    auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT, ROT>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int         dev = 0;
@@ -911,18 +947,18 @@ template <class V, class P, int CB, int DIR, bool NT> hipError_t launch_dual(con
     if (grid > ntiles) grid = ntiles;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * P::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
-                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * P::T);
     return hipSuccess;
 }
 
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, bool ROT = false> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
     constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB>::LDS_BYTES;
-    auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT>;
+    auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT, ROT>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int         dev = 0;
@@ -943,7 +979,7 @@ template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool
     if (grid > ntiles) grid = ntiles;
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * PH::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
-                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale);
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * PH::T);
     return hipSuccess;
@@ -1011,6 +1047,16 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
     if (L.ntiles <= 0) return hipSuccess;
     if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
     const bool general = (L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0;
+    // rotated rows (RotMap): whole tiles move inside their rows, so the rotation and the row length must be multiples of the
+    // widest tile used below (a full line), sides must have unit column stride, and the launch must be a fast-path one
+    const bool rot = L.rot.in_mode != 0 || L.rot.out_mode != 0;
+    if (rot) {
+        constexpr int LINE = 128 / (int)sizeof(V);
+        const bool ok = !general && L.rot.rot > 0 && L.rot.rot % LINE == 0 && (L.rot.mask + 1) % LINE == 0 && ((L.rot.mask + 1) & L.rot.mask) == 0 &&
+                        L.ncols == L.rot.mask + 1 && (L.rot.in_mode == 0 || (L.imap.cstride == 1 && L.itile.b_stride == 1)) &&
+                        (L.rot.out_mode == 0 || (L.omap.cstride == 1 && L.otile.b_stride == 1));
+        if (!ok) return hipErrorInvalidValue;
+    }
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
@@ -1026,8 +1072,11 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 return e && *e && *e != '0';
             }();
             const bool transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
-            if (!no_dual && !general && transposed && L.imap.blk % P::T == 0 && L.ncols % (2 * CBC) == 0 && L.imap.cstride == 1 && L.itile.b_stride == 1)
+            if (!no_dual && !general && transposed && L.imap.blk % P::T == 0 && L.ncols % (2 * CBC) == 0 && L.imap.cstride == 1 && L.itile.b_stride == 1 &&
+                (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
+                if (rot) return L.dir > 0 ? launch_dual<V, P, CBC, +1, true, true>(L, stream) : launch_dual<V, P, CBC, -1, true, true>(L, stream);
                 return L.dir > 0 ? launch_dual<V, P, CBC, +1, true>(L, stream) : launch_dual<V, P, CBC, -1, true>(L, stream);
+            }
         }
         if constexpr (!std::is_void<PH>::value) {
             // full-line tiles through the DIF split whenever both sides keep the 8 (16 fp32) columns of a line together
@@ -1042,7 +1091,16 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
             const bool sin = (L.hints & FFT_HINT_STREAM_IN) != 0, sout = (L.hints & FFT_HINT_STREAM_OUT) != 0;
             // (the kernel keeps its per-point block offsets in 32 bits)
             const bool fits32 = axis_max_offset(L.imap, P::N) < (1ll << 32) && axis_max_offset(L.omap, P::N) < (1ll << 32);
-            if (!no_dif2 && lines && even && fits32 && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0) {
+            const bool rot_tile = rot && L.rot.in_mode != 2 && L.rot.out_mode != 2;  // the kernel rotates whole tiles only
+            if (!no_dif2 && lines && even && fits32 && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0 && (!rot || rot_tile)) {
+                if (rot) {
+                    if (L.dir > 0) {
+                        if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true, true>(L, stream);
+                        return launch_dif2<V, PH, CBF, +1, false, false, true, true, true>(L, stream);
+                    }
+                    if (sin) return launch_dif2<V, PH, CBF, -1, true, false, true, true, true>(L, stream);
+                    return launch_dif2<V, PH, CBF, -1, false, false, true, true, true>(L, stream);
+                }
                 if (L.dir > 0) {
                     if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true>(L, stream);
                     if (sin) return launch_dif2<V, PH, CBF, +1, true, false, true, true>(L, stream);
@@ -1052,6 +1110,28 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 if (sout) return launch_dif2<V, PH, CBF, -1, false, true, true, true>(L, stream);
                 return launch_dif2<V, PH, CBF, -1, false, false, true, true>(L, stream);
             }
+        }
+        if (rot) {  // the rotated twins of the fast-path variants: forward Y stores rotated tiles (0, 1), forward X loads rotated
+                    // points (2, 0); backward X stores rotated points (0, 2), backward Y loads rotated tiles (1, 0)
+            const int im = L.rot.in_mode, om = L.rot.out_mode;
+            if (L.dir > 0 && im == 0 && om == 1) {
+                if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneColsStreamOut, 0, 1>>(L, stream);
+                return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneCols, 0, 1>>(L, stream);
+            }
+            if (L.dir > 0 && im == 2 && om == 0) {
+                if constexpr (can_stage)
+                    if (staged) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TT, 2, 0>>(L, stream);
+                return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneCols, 2, 0>>(L, stream);
+            }
+            if (L.dir < 0 && im == 0 && om == 2) {
+                if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneColsStreamIn, 0, 2>>(L, stream);
+                return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneCols, 0, 2>>(L, stream);
+            }
+            if (L.dir < 0 && im == 1 && om == 0) {
+                if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneColsStreamIn, 1, 0>>(L, stream);
+                return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneCols, 1, 0>>(L, stream);
+            }
+            return hipErrorInvalidValue;
         }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
@@ -1085,6 +1165,11 @@ template <class P> bool make_pair_launch(const FftLaunch& L, FftLaunch& out) {
     auto even = [](long long v) { return (v & 1) == 0; };
     out = L;
     out.ncols = L.ncols / 2;
+    if (L.rot.in_mode != 0 || L.rot.out_mode != 0) {  // rotated rows: the same rotation in units of pairs
+        if ((L.rot.rot & 1) || !(L.rot.mask & 1)) return false;
+        out.rot.rot = L.rot.rot / 2;
+        out.rot.mask = (L.rot.mask + 1) / 2 - 1;
+    }
     // contiguous-column side: every stride halves, columns stay unit-stride
     auto contiguous = [&](const AxisMap& m, const TileMap& t, AxisMap& mo, TileMap& to) {
         if (m.cstride != 1 || t.b_stride != 1) return false;

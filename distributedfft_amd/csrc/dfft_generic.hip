@@ -202,6 +202,7 @@ template <class V> hipError_t launch_generic_t(const FftLaunch& Lin, hipStream_t
 }  // namespace
 
 hipError_t launch_generic(const FftLaunch& L, hipStream_t stream) {
+    if (L.rot.in_mode != 0 || L.rot.out_mode != 0) return hipErrorInvalidValue;  // rotated rows: tuned kernels only
     if (L.dtype == F64) return launch_generic_t<double2>(L, stream);
     if (L.dtype == F32) return launch_generic_t<float2>(L, stream);
     return hipErrorInvalidValue;

@@ -31,6 +31,20 @@ struct TileMap {
     long long b_stride;
 };
 
+// Row rotation inside the exchange buffers (P > 1 plans): row (plane x, y) of a packed / received slab is stored rotated by
+// rot * x elements inside its N2 elements.  With power-of-two extents the X pass's tile is N0 segments of 128 bytes exactly
+// ys * N2 * S bytes apart (1 MiB at 512^3 fp64 / P = 4), which all fall on the same memory channels; the rotation moves
+// consecutive planes' segments to different lines at no cost in bytes (the single-GPU plan pads its own hand-over buffer
+// instead).  The Y pass applies it per tile (the plane is the tile's slow index), the X pass per FFT point (the plane is the
+// FFT index).  Messages keep their sizes and offsets, only the order of the elements inside a row changes, and only between
+// the two passes of this library -- no caller-visible buffer is affected.
+struct RotMap {
+    int in_mode, out_mode;  // 0: none; 1: by the tile's plane index a + a0; 2: by the FFT point index
+    int rot;                // elements (units of one V) per plane
+    int mask;               // row length - 1 in units of V (row length is a power of two)
+    int a0;                 // global index of the launch's plane 0 (mode 1)
+};
+
 struct FftLaunch {
     int         dtype;  // DType
     int         n;      // FFT length
@@ -51,6 +65,7 @@ struct FftLaunch {
     double      scale;    // results are multiplied by this before the store (0 or 1 = no scaling)
     int         blocks_per_cu_limit;  // > 0: cap the persistent grid at this many blocks per CU (leaves room for a
                                       // kernel running concurrently on another stream)
+    RotMap      rot;                  // row rotation of an exchange-buffer side (all zero: none)
     int         grid_limit;           // > 0: cap the persistent grid at this many workgroups (HBM writes run faster from
                                       // fewer concurrent writers, profiles/r02/README.md section 1; tuning knob)
 };

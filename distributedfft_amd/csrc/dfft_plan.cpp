@@ -223,6 +223,9 @@ struct dfft_plan_s {
     // allocations usually share one; profiles/r03/README.md section 1, tools/xprobe.hip), so tuning times the X-pass kernel
     // alone on a few candidate allocations -- spacer allocations in between move the candidates across region boundaries --
     // and keeps the one on which it ran fastest.
+    // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
+    // received planes are a power-of-two distance apart.  0 = off.
+    int                     rot_elems = 0;
     std::vector<float>      w_ms;            // report: X-pass time of every candidate tried (w_ms[w_kept] is the kept one)
     int                     w_kept = -1;
     float                   w_final_ms = 0.f;  // the kept candidate re-timed after the others were freed
@@ -324,6 +327,12 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.a_first = x0;
     L.hints = hints;
     L.ncols = (int)n2;
+    if (use_packed && p->rot_elems > 0) {  // the packed side's rows are rotated by the plane's global index
+        L.rot.rot = p->rot_elems;
+        L.rot.mask = (int)n2 - 1;
+        L.rot.a0 = (int)p->sx.start(p->me);
+        (packed_side_is_out ? L.rot.out_mode : L.rot.in_mode) = 1;
+    }
     static const int ygrid = env_grid("DFFT_Y_GRID");
     L.grid_limit = ygrid;
     return check_launch(launch_fft(L, p->stream), "Y pass");
@@ -371,6 +380,11 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     L.na = ys;
     L.scale = p->scale;
     L.ncols = (int)n2;
+    if (p->rot_elems > 0 && p->exch && !keep_slab && !slab_lay) {  // the slab side is an exchange buffer with rotated rows
+        L.rot.rot = p->rot_elems;
+        L.rot.mask = (int)n2 - 1;
+        (p->direction == DFFT_FORWARD ? L.rot.in_mode : L.rot.out_mode) = 2;
+    }
     static const int xgrid = env_grid("DFFT_X_GRID");
     L.grid_limit = xgrid;
     return check_launch(launch_fft(L, p->stream), "X pass");
@@ -1020,6 +1034,21 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                 if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] plan buffers: in %p out %p bufferDev1 %p work %p\n", in, out, p->buf1, p->wbuf);
             }
         }
+    }
+    {
+        // Rotated rows in the exchange buffers (dfft_plan_s::rot_elems): the same remedy for the P > 1 pipeline that the padded
+        // hand-over buffer is for the single-GPU one.  Every rank derives it from (N, P, precision, flags) alone -- both ends of
+        // every message must agree.  Where: fused, even splits, tuned kernels on all three axes, rows of whole lines and a
+        // power-of-two length, received planes a multiple of 256 KiB apart (other strides spread over the channels by
+        // themselves).  DFFT_ROT=0 / 1 forces it off / on (wherever it is possible).
+        const char*     re = getenv("DFFT_ROT");
+        const long long S = (long long)elem_bytes(dtype);
+        const bool      possible = p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis && n0 % total_devices == 0 &&
+                              n1 % total_devices == 0 && (n2 & (n2 - 1)) == 0 && (n2 * S) % 128 == 0 && n2 * S >= 256 && n2 < (1ll << 30) &&
+                              fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2);
+        const long long ysub = p->ys / std::max(1, p->ycuts);
+        const bool      pays = (ysub * n2 * S) % (256ll << 10) == 0;
+        if (possible && !(re && *re == '0') && (pays || (re && *re == '1'))) p->rot_elems = (int)(3 * 128 / S);
     }
     {
         // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of NATURAL planes that

@@ -423,6 +423,42 @@ def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, yparts, monkeypa
         assert np.abs(over[g][:cnt].reshape(inputs[g].shape) / float(n0 * n1 * n2) - inputs[g]).max() < 1e-10
 
 
+# shapes whose exchange buffers can carry rotated rows (even splits, power-of-two N2 of at least two cache lines), chosen to
+# reach every kernel with a rotated side: 512-point tiles (staged X pass), 16 points per thread (1024), radix-3 Y axis (768),
+# the 2048-point DIF-split Y pass and paired-tile X pass, half-line fallbacks, fp32 column pairs and scalar fp32 columns
+ROT_SHAPES = [((64, 64, 64), 2), ((64, 64, 64), 4), ((128, 128, 32), 8), ((512, 8, 32), 2), ((1024, 8, 64), 4), ((16, 768, 16), 2),
+              ((2048, 8, 16), 2), ((2048, 8, 8), 4), ((8, 2048, 16), 2), ((16, 2048, 32), 4), ((32, 32, 16), 2), ((24, 40, 256), 4)]
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("N,P", ROT_SHAPES)
+def test_rotated_exchange_rows_vs_oracle(gpu, N, P, prec, monkeypatch):
+    """DFFT_ROT=1: the rows of the packed send buffer / the received slab are rotated by three cache lines per X plane (the
+    Y pass rotates whole tiles, the X pass every point by its plane) -- the channel-conflict remedy of the P > 1 pipeline,
+    switched on by itself only where received planes are a multiple of 256 KiB apart.  Results must equal the un-rotated
+    pipeline's bit for bit (serial and overlapped, forward and backward) and the oracle's within the tolerance."""
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=4242 + P + n0)
+    ref = so.fftn_reference(x, P)
+    inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    scale = max(np.abs(r).max() for r in ref)
+    monkeypatch.setenv("DFFT_ROT", "0")
+    plain, _ = _run_plans(gpu, N, P, prec, x, +1, api.PLAN_INPUT_FROM_IN, inputs)
+    bplain, _ = _run_plans(gpu, N, P, prec, None, -1, api.PLAN_INPUT_FROM_IN, [r for r in ref])
+    monkeypatch.setenv("DFFT_ROT", "1")
+    for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP, 0):
+        rot, _ = _run_plans(gpu, N, P, prec, x, +1, flags, inputs)
+        for d in range(P):
+            cnt = ref[d].size
+            assert np.array_equal(rot[d][:cnt], plain[d][:cnt]), f"forward N={N} P={P} flags={flags} dev={d}"
+            assert np.abs(rot[d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < TOL[prec]
+        brot, _ = _run_plans(gpu, N, P, prec, None, -1, flags, [r for r in ref])
+        for g in range(P):
+            cnt = inputs[g].size
+            assert np.array_equal(brot[g][:cnt], bplain[g][:cnt]), f"backward N={N} P={P} flags={flags} dev={g}"
+
+
 def test_in_place_plans_and_reload(gpu):
     """out == None / out == in selects the in-place mode (bufferDev2 = in, fft_mpi_3d_api.cpp:68-71); input is captured
     at plan time and can be replaced through bufferDev1 (fftSpeed3d_c2c.cpp:78) for repeated executes."""
