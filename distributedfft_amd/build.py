@@ -69,6 +69,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     units.append((CSRC / "dfft_kernels.hip", OBJ / "dfft_kernels.o", []))
     units.append((CSRC / "dfft_generic.hip", OBJ / "dfft_generic.o", []))
     units.append((CSRC / "dfft_long.hip", OBJ / "dfft_long.o", []))
+    units.append((CSRC / "dfft_zy.hip", OBJ / "dfft_zy.o", []))
     for name in ("dfft_plan", "dfft_exchange", "dfft_bootstrap", "dfft_alloc"):
         units.append((CSRC / f"{name}.cpp", OBJ / f"{name}.o", ["-x", "hip"]))
 

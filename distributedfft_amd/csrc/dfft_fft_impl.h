@@ -513,7 +513,9 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     // point rotation: plane of point k of this thread = j + T * k, so its rotation is (rot_j + k * rot_t) mod row length
     const int rot_j = Tune::ROT ? (rm.rot * j) & rm.mask : 0, rot_t = Tune::ROT ? (rm.rot * T) & rm.mask : 0;
     // loads the E points of the tile group starting at t into dst (zeros for tiles / columns past the end)
-    auto load_tile = [&](unsigned t, V* dst) {
+    // (points [K0, K1) of the thread only: the partial prefetch below)
+    auto load_part = [&](unsigned t, V* dst, auto k0c, auto k1c) {
+        constexpr int K0 = decltype(k0c)::value, K1 = decltype(k1c)::value;
         const unsigned tile = map_tile(t + g);
         bool ok = tile < ntiles;
         const unsigned al = tile / tiles_per_a;
@@ -527,23 +529,37 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         const GV* ip = in + (long long)a * itile.a_stride + (long long)cb0 * itile.b_stride;
         if (ok) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
+            for (int k = K0; k < K1; ++k) {
                 long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
                 if constexpr (Tune::ROT_IN == 2) off += (long long)(((cb0 + rot_j + k * rot_t) & rm.mask) - cb0);
-                dst[k] = VT::from_g(gload<Tune::NTL>(ip + off));
+                dst[k - K0] = VT::from_g(gload<Tune::NTL>(ip + off));
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < E; ++k) dst[k] = VT::zero();
+            for (int k = K0; k < K1; ++k) dst[k - K0] = VT::zero();
         }
     };
+    auto load_tile = [&](unsigned t, V* dst) { load_part(t, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}); };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
     constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS) && KG::THREADS <= 512;
+    // 16 points per thread (1024- and 2048-point columns): a whole second register set does not fit (64 VGPRs: 4.6 -> 3.7 TB/s,
+    // round 1), but the kernels leave room for HALF of one -- the first 8 points of the next tile are fetched underneath the
+    // current tile's exchanges and stores, the other 8 at the top of the next iteration.  DFFT_HALF_PREFETCH=0 compiles it out.
+#ifndef DFFT_HALF_PREFETCH
+#define DFFT_HALF_PREFETCH 1
+#endif
+    constexpr int PF = PREFETCH ? E : (DFFT_HALF_PREFETCH && Tune::PREFETCH && E == 16 && sizeof(V) == 16 && KG::THREADS <= 512 && KG::PH == 1 ? E / 2 : 0);
+    constexpr bool PARTIAL = PF > 0 && PF < E;
+    using K0 = std::integral_constant<int, 0>;
+    using KP = std::integral_constant<int, PF>;
+    using KE = std::integral_constant<int, E>;
     V v[E];
-    V vnext[PREFETCH ? E : 1];
+    V vnext[PF > 0 ? PF : 1];
     if constexpr (PREFETCH) {
         if (blockIdx.x * G < ntiles) load_tile(blockIdx.x * G, v);
+    } else if constexpr (PARTIAL) {
+        if (blockIdx.x * G < ntiles) load_part(blockIdx.x * G, v, K0{}, KP{});
     }
     for (unsigned t0 = blockIdx.x * G; t0 < ntiles; t0 += tstep) {
         const unsigned tile = map_tile(t0 + g);
@@ -559,6 +575,9 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         if constexpr (PREFETCH) {
             // issue the next tile's HBM loads now; they complete underneath this tile's exchanges and stores
             if (t0 + tstep < ntiles) load_tile(t0 + tstep, vnext);
+        } else if constexpr (PARTIAL) {
+            load_part(t0, v + PF, KP{}, KE{});                                   // the rest of this tile
+            if (t0 + tstep < ntiles) load_part(t0 + tstep, vnext, K0{}, KP{});  // the first points of the next one
         } else {
             load_tile(t0, v);
         }
@@ -623,9 +642,9 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
                 gstore<Tune::NTS>(op + off, VT::to_g(cscale(v[k], sc)));
             }
         }
-        if constexpr (PREFETCH) {
+        if constexpr (PF > 0) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = vnext[k];
+            for (int k = 0; k < PF; ++k) v[k] = vnext[k];
         }
     }
 }
@@ -763,7 +782,7 @@ template <class V, class PH, int CB> struct Dif2Geom {
 };
 // BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
 // which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, bool ROT = false>
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(1)))
 fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
@@ -816,7 +835,7 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
         int cbi = (int)(b * CB), cbo = (int)(b * CB);
-        if constexpr (ROT) {
+        if constexpr (ROT == 1) {
             const int r = rm.rot * (int)(a + (unsigned)rm.a0);
             if (rm.in_mode == 1) cbi = (cbi + r) & rm.mask;
             if (rm.out_mode == 1) cbo = (cbo + r) & rm.mask;
@@ -953,28 +972,33 @@ template <class V, class P, int CB, int DIR, bool NT, bool ROT = false> hipError
     return hipSuccess;
 }
 
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, bool ROT = false> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
     constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB>::LDS_BYTES;
     auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT, ROT>;
-    static std::atomic<bool> attr_set[64];
-    static std::mutex        setup_mutex;
+    static std::atomic<int> blocks_per_cu[64];  // 0 = not set up on that device yet
+    static std::mutex       setup_mutex;
     int         dev = 0;
     hipError_t  e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
+    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
         std::lock_guard<std::mutex> lk(setup_mutex);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * PH::T);
-        attr_set[dev].store(true, std::memory_order_release);
+        int occ = 0;  // a half tile of 64 KiB (1024 points) leaves room for a second workgroup when the registers allow it
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, CB * PH::T, LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
     }
     const long long tiles_per_a = L.ncols / CB, ntiles = L.na * tiles_per_a;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
-    long long grid = device_info().cus;
+    long long grid = (long long)device_info().cus * blocks_per_cu[dev].load(std::memory_order_relaxed);
     if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
     if (grid > ntiles) grid = ntiles;
     (void)hipGetLastError();
@@ -1086,20 +1110,31 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 const char* e = getenv("DFFT_NO_DIF2");
                 return e && *e && *e != '0';
             }();
-            const bool lines = L.imap.cstride == 1 && L.omap.cstride == 1 && L.itile.b_stride == 1 && L.otile.b_stride == 1;
+            // both sides keep the 8 (16 fp32) columns of a line together.  (The transposed [..][z][kx] side of the forward X pass
+            // was tried on this kernel too -- a thread's results 2m and 2m + 1 are neighbours in kx, stored 16 bytes at a time by the
+            // two half transforms: 2.2 TB/s against 4.6-4.8 for the staged / paired-tile kernels at 1024 and 2048 points,
+            // profiles/r03/experiments/xpass_variants.log -- and removed.)
+            const bool lines_in = L.imap.cstride == 1 && L.itile.b_stride == 1;
+            const bool lines_out = L.omap.cstride == 1 && L.otile.b_stride == 1;
+            constexpr bool transposed_out = false;
             const bool even = L.ncols % CBF == 0 && L.imap.last_delta == 0 && L.omap.last_delta == 0;
             const bool sin = (L.hints & FFT_HINT_STREAM_IN) != 0, sout = (L.hints & FFT_HINT_STREAM_OUT) != 0;
             // (the kernel keeps its per-point block offsets in 32 bits)
             const bool fits32 = axis_max_offset(L.imap, P::N) < (1ll << 32) && axis_max_offset(L.omap, P::N) < (1ll << 32);
-            const bool rot_tile = rot && L.rot.in_mode != 2 && L.rot.out_mode != 2;  // the kernel rotates whole tiles only
-            if (!no_dif2 && lines && even && fits32 && !staged && L.imap.blk % PH::T == 0 && L.omap.blk % (2 * PH::T) == 0 && (!rot || rot_tile)) {
+            const bool rot_tile = rot && L.rot.in_mode != 2 && L.rot.out_mode != 2;  // whole tiles move (Y passes)
+            static const int dif2_min = [] {  // DFFT_DIF2_MIN=<n>: lengths from n on use the split (default 2048; 1024 has a half plan too)
+                const char* e = getenv("DFFT_DIF2_MIN");
+                return e ? atoi(e) : 2048;
+            }();
+            if (!no_dif2 && P::N >= dif2_min && lines_in && (lines_out || transposed_out) && even && fits32 && L.imap.blk % PH::T == 0 &&
+                L.omap.blk % (2 * PH::T) == 0 && (!rot || rot_tile)) {
                 if (rot) {
                     if (L.dir > 0) {
-                        if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true, true>(L, stream);
-                        return launch_dif2<V, PH, CBF, +1, false, false, true, true, true>(L, stream);
+                        if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true, 1>(L, stream);
+                        return launch_dif2<V, PH, CBF, +1, false, false, true, true, 1>(L, stream);
                     }
-                    if (sin) return launch_dif2<V, PH, CBF, -1, true, false, true, true, true>(L, stream);
-                    return launch_dif2<V, PH, CBF, -1, false, false, true, true, true>(L, stream);
+                    if (sin) return launch_dif2<V, PH, CBF, -1, true, false, true, true, 1>(L, stream);
+                    return launch_dif2<V, PH, CBF, -1, false, false, true, true, 1>(L, stream);
                 }
                 if (L.dir > 0) {
                     if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true>(L, stream);

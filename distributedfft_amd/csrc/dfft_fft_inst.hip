@@ -34,6 +34,7 @@ template <> struct PlanRows32<3125> { using type = Plan<3125, 5, 5, 5, 5, 5, 5>;
 // Half plan for the DIF-split full-line column tiles (launch_plan): 2048-point columns run as two 1024-point transforms
 template <int N> struct PlanHalf { using type = void; };
 template <> struct PlanHalf<2048> { using type = PlanFor<1024>::type; };
+template <> struct PlanHalf<1024> { using type = PlanFor<512>::type; };  // used from DFFT_DIF2_MIN=1024 on (measurement switch)
 
 template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
     if (!L.cols) {

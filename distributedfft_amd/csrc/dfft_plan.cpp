@@ -25,6 +25,7 @@
 
 #include "dfft_internal.h"
 #include "dfft_long.h"
+#include "dfft_zy.h"
 
 namespace dfft {
 
@@ -223,6 +224,10 @@ struct dfft_plan_s {
     // allocations usually share one; profiles/r03/README.md section 1, tools/xprobe.hip), so tuning times the X-pass kernel
     // alone on a few candidate allocations -- spacer allocations in between move the candidates across region boundaries --
     // and keeps the one on which it ran fastest.
+    // t0 as one persistent launch (dfft_zy.hip) instead of two launches per cache chunk: single-GPU fused plans in fp64 whose Y and
+    // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
+    ZyCtl*                  zy_ctl = nullptr;
+    bool                    zy_on = false;
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.
     int                     rot_elems = 0;
@@ -426,6 +431,42 @@ struct StageClock {
         if (rc_) return rc_;  \
     } while (0)
 
+// t0 of a single-GPU fused plan as one launch: forward src -> wbuf (Z) -> wbuf (Y); backward wbuf (Y) -> dst (Z)
+static int launch_zy_stage(dfft_plan_s* p, const void* src, void* dst) {
+    const void *twz = nullptr, *twy = nullptr;
+    DFFT_TRY(get_twiddles((int)p->N[2], p->dtype, &twz));
+    DFFT_TRY(get_twiddles((int)p->N[1], p->dtype, &twy));
+    ZyLaunch L;
+    std::memset(&L, 0, sizeof(L));
+    L.dtype = p->dtype;
+    L.n1 = (int)p->N[1];
+    L.n2 = (int)p->N[2];
+    L.dir = p->direction;
+    L.src = src;
+    L.w = p->wbuf;
+    L.dst = dst;
+    L.src_plane = L.dst_plane = p->N[1] * p->N[2];
+    L.w_plane = p->wl.plane;
+    L.nplanes = p->xs;
+    L.chunk = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
+    L.ctl = p->zy_ctl;
+    L.twz = twz;
+    L.twy = twy;
+    DFFT_HIP_TRY(hipMemsetAsync(p->zy_ctl, 0, 256 + sizeof(unsigned) * (size_t)p->xs, p->stream));
+    return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
+}
+
+// after the plan's stream has drained: did a one-launch stage give up (a consumer waited > 20 ms for its producers)?
+static int zy_check(dfft_plan_s* p) {
+    if (!p->zy_on || !p->zy_ctl) return DFFT_OK;
+    unsigned err = 0;
+    DFFT_HIP_TRY(hipMemcpy(&err, &p->zy_ctl->error, sizeof(err), hipMemcpyDeviceToHost));
+    if (err == 0) return DFFT_OK;
+    p->zy_on = false;  // two launches per chunk from now on
+    return fail(DFFT_EHIP, "the one-launch YZ stage timed out waiting for its own producers; the result of that execute is invalid, "
+                           "later executes of this plan use the two-launch stage (DFFT_T0_ONE_LAUNCH=0 selects it from the start)");
+}
+
 static int execute_forward(dfft_plan_s* p, bool sync) {
     const bool      fused = !(p->flags & DFFT_PLAN_UNFUSED);
     const long long n1 = p->N[1], n2 = p->N[2], n0 = p->N[0];
@@ -496,7 +537,11 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    for (long long x0 = 0; x0 < p->xs; x0 += cp) {
+    const bool      one_launch = p->zy_on && fused && !y_packs && p->wbuf && zdst == p->wbuf;
+    if (one_launch) {  // the same chunk phases inside ONE persistent launch (dfft_zy.hip)
+        DFFT_TRY(launch_zy_stage(p, zsrc, nullptr));
+    }
+    for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {
         const long long nx = std::min(cp, p->xs - x0);
         DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                           (chunked && zsrc != zdst) ? FFT_HINT_STREAM_IN : 0, 1.0, lnat, lz, lz ? n1 : 0));
@@ -659,7 +704,9 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    for (long long x0 = 0; x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
+    const bool one_launch = p->zy_on && xw && ydst == p->wbuf;
+    if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, ybuf));  // Y columns in place, then Z rows into the result: one launch
+    for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
         else if (xw) DFFT_TRY(launch_y(p, p->wbuf, p->wbuf, false, false, x0, nx, 0, &yl, &yl));
@@ -1075,6 +1122,15 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (cpe && atoll(cpe) > 0) p->chunk_planes = atoll(cpe);
         if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
+    {
+        // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
+        const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
+        if (!(oe && *oe == '0') && p->wbuf && !p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && p->wl.pitch == n2 &&
+            zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
+            if (hipMalloc((void**)&p->zy_ctl, sizeof(ZyCtl)) == hipSuccess) p->zy_on = true;
+            else (void)hipGetLastError();
+        }
+    }
     if (p->long_axis) {
         p->chunk_planes = 0;  // the four-step passes work on the whole slab
         e = hipMalloc(&p->lbuf, (size_t)p->max_count * elem_bytes(dtype));
@@ -1312,6 +1368,10 @@ int dfft_plan_tune_report(dfft_plan_t plan, int max_n, double* ms, int* kept, do
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    {
+        const int rc = zy_check(plan);
+        if (rc) return rc;
+    }
     if (plan->comm) return comm_check(plan->comm);
     return DFFT_OK;
 }
@@ -1319,6 +1379,10 @@ int dfft_plan_sync(dfft_plan_t plan) {
 int dfft_stage_times(dfft_plan_t plan, double t[4]) {
     if (!plan || !t) return fail(DFFT_EINVAL, "dfft_stage_times: bad arguments");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    {
+        const int rc = zy_check(plan);
+        if (rc) return rc;
+    }
     if (plan->comm) {
         const int rc = comm_check(plan->comm);
         if (rc) return rc;
@@ -1381,6 +1445,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->rbuf) hipFree(plan->rbuf);
     if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
+    if (plan->zy_ctl) hipFree(plan->zy_ctl);
     delete plan;
     return DFFT_OK;
 }

@@ -1,0 +1,287 @@
+// dfft_zy.hip -- t0 (batched 2D YZ FFT of every owned plane; reference fftZY, fft_mpi_3d_api.cpp:466-522) as ONE persistent launch.
+//
+// The plan's default t0 alternates two launches per 256 MiB Infinity-Cache chunk of planes (Z rows, then Y columns: 16 launches at
+// 512^3 fp64).  This kernel runs the same phases -- all row units of a chunk, then all column units of the same chunk -- inside
+// one launch: work items are handed out by a global ticket counter in that order; a row unit publishes its rows with write-through
+// (sc1) stores and one relaxed agent-scope increment of its plane's counter; a column unit starts when its plane's counter shows
+// that every row unit of the plane has published, and reads the rows with sc1 loads (MI355X_MICROARCH.md, inter-workgroup
+// hand-off: "16 B sc1 stores AND sc1 loads" -- no fences; a release / acquire fence per unit cost 0.15-0.2 ms of a 1.37 ms stage
+// in the experiments of round 2, profiles/r02/experiments/zy_stream_first_run.log).  What is saved is the 15 launch boundaries
+// inside the stage (the phases overlap at their edges instead of draining the GPU): 1.365 -> 1.337 ms in the experiment that
+// preceded this file.  The inverse transform runs the mirror image (column units first, then row units into the result buffer).
+//
+// The arithmetic is the library's own (run_stages of dfft_fft_impl.h with the same plans and register twiddles), so results are
+// bit-identical to the two-launch path -- tests/test_gpu_parity.py::test_one_launch_t0_is_bit_identical.
+//
+// Deadlock freedom: tickets are taken in order by RUNNING workgroups only; a producer unit never waits; a consumer unit waits only
+// for producer units with smaller tickets, and a workgroup never holds an unprocessed item while it waits (the next item is
+// prefetched only if its dependency is already satisfied).  Every spin is bounded by the wall clock; a time-out sets ctl->error,
+// every workgroup leaves, and the host reports it at the next synchronisation (and goes back to the two-launch path).
+//
+// Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes), single-GPU
+// fused plans with the padded hand-over buffer.  Everything else keeps the chunk loop.
+#include "dfft_fft_impl.h"
+#include "dfft_zy.h"
+
+namespace dfft {
+
+namespace {
+
+typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
+#define DFFT_ZY_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+// DIR = +1: producers = Z rows (src -> w), consumers = Y columns (w in place)
+// DIR = -1: producers = Y columns (w in place), consumers = Z rows (w -> dst)
+template <class PZ, class PY, int DIR>
+__global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
+zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
+                long long src_plane, long long w_plane, long long dst_plane, unsigned nplanes, unsigned chunk) {
+    using V = double2;
+    constexpr int CB = 8;  // column tiles of one cache line
+    constexpr int THREADS = CB * PY::T;
+    constexpr int N2 = PZ::N, N1 = PY::N, E = PZ::E, TZ = PZ::T, TY = PY::T;
+    static_assert(PZ::E == PY::E, "one register set serves both item kinds");
+    static_assert(TZ <= 64 && 64 % TZ == 0 && THREADS % TZ == 0, "rows: one FFT inside one wavefront");
+    constexpr int GR = THREADS / TZ;  // rows per row unit
+    static_assert(N1 % GR == 0 && N2 % CB == 0, "a plane must split into whole units");
+    constexpr unsigned UZ = N1 / GR, UY = N2 / CB;
+    constexpr unsigned UA = DIR > 0 ? UZ : UY, UB = DIR > 0 ? UY : UZ, BB = UA + UB;  // producer / consumer units per plane
+    constexpr bool     TWPOW = true;
+    constexpr int      ROW_LDS = N2 + N2 / 8;  // padded row (lds_index<1, true>)
+    constexpr unsigned LIMIT = 20u * 1000u * 100u;  // 20 ms of the 100 MHz wall clock
+
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    unsigned* shw = reinterpret_cast<unsigned*>(dfft_smem);  // [0] ticket broadcast, [1] dependency state
+    V*        lds = reinterpret_cast<V*>(dfft_smem + 64);
+
+    const int tid = threadIdx.x;
+    const int gz = tid / TZ, jz = tid % TZ;  // row unit: row gz of the unit, butterfly id jz
+    const int cy = tid % CB, jy = tid / CB;  // column unit: column cy of the tile, butterfly id jy
+    V*        lds_row = lds + gz * ROW_LDS;
+
+    constexpr int TWNZ = TwTotal<PZ, TWPOW>::value, TWNY = TwTotal<PY, TWPOW>::value;
+    V twzr[TWNZ > 0 ? TWNZ : 1], twyr[TWNY > 0 ? TWNY : 1];
+    load_twiddles<V, PZ, 0, DIR, TWPOW>(twzr, twz, jz);
+    load_twiddles<V, PY, 0, DIR, TWPOW>(twyr, twy, jy);
+
+    const unsigned CH = chunk;
+    const unsigned nchunks = (nplanes + CH - 1) / CH;
+    const unsigned total = nchunks * CH * BB;  // tickets (some of the last chunk's are empty)
+    enum { NONE = 0, PROD = 1, CONS = 2 };
+    struct Item {
+        unsigned ticket, kind, plane, unit;
+    };
+    auto decode = [&](unsigned t) -> Item {
+        Item it{t, NONE, 0u, 0u};
+        if (t >= total) return it;
+        const unsigned c = t / (CH * BB), r = t - c * (CH * BB);
+        if (r < CH * UA) {
+            const unsigned pl = c * CH + r / UA;
+            if (pl < nplanes) it = Item{t, PROD, pl, r % UA};
+        } else {
+            const unsigned r2 = r - CH * UA, pl = c * CH + r2 / UB;
+            if (pl < nplanes) it = Item{t, CONS, pl, r2 % UB};
+        }
+        return it;
+    };
+    auto share = [&](unsigned value_of_thread0) -> unsigned {
+        if (tid == 0) shw[0] = value_of_thread0;
+        __syncthreads();
+        const unsigned t = shw[0];
+        __syncthreads();
+        return t;
+    };
+    auto take = [&]() -> unsigned {  // thread 0: the next ticket (the atomic's latency hides behind the caller's work)
+        return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) : 0u;
+    };
+    // dependency of a consumer unit: every producer unit of its plane has published.  wait = false: one poll only.
+    auto ready = [&](const Item& it, bool wait) -> bool {
+        if (it.kind != CONS) return true;
+        if (tid == 0) {
+            unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) >= UA ? 1u : 0u;
+            if (!ok && wait) {
+                const unsigned long long t0 = wall_clock64();
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) >= UA) {
+                        ok = 1u;
+                        break;
+                    }
+                    if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) break;
+                    if (wall_clock64() - t0 > LIMIT) {
+                        __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+                        break;
+                    }
+                }
+            }
+            shw[1] = ok;
+        }
+        __syncthreads();
+        const bool ok = shw[1] != 0u;
+        __syncthreads();
+        return ok;
+    };
+    auto wrsrc = [&](unsigned plane) {  // buffer descriptor of one plane of w (offsets inside a plane fit 32 bits)
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(w + (long long)plane * w_plane), 0, (int)((size_t)N1 * N2 * sizeof(V)), 0x00020000);
+    };
+    constexpr bool ROWS_PRODUCE = DIR > 0;  // which kind of unit hands its results over through w
+    // ---- row units (Z): forward src -> w (sc1 stores), backward w (sc1 loads) -> dst
+    auto load_rows = [&](unsigned plane, unsigned un, V* d) {
+        if constexpr (ROWS_PRODUCE) {
+            const V* ip = src + (long long)plane * src_plane + (long long)(un * GR + gz) * N2 + jz;
+#pragma unroll
+            for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + TZ * k);  // streamed input
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const unsigned elem = (unsigned)((un * GR + gz) * N2 + jz + TZ * k);
+                d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
+            }
+        }
+    };
+    auto store_rows = [&](unsigned plane, unsigned un, const V* v) {
+        if constexpr (ROWS_PRODUCE) {
+            const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const unsigned elem = (unsigned)((un * GR + gz) * N2 + jz + TZ * k);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
+            }
+        } else {
+            V* op = dst + (long long)plane * dst_plane + (long long)(un * GR + gz) * N2 + jz;
+#pragma unroll
+            for (int k = 0; k < E; ++k) op[TZ * k] = v[k];
+        }
+    };
+    // ---- column units (Y), in place on w: forward sc1 loads / plain stores, backward plain loads / sc1 stores
+    auto load_cols = [&](unsigned plane, unsigned un, V* d) {
+        if constexpr (ROWS_PRODUCE) {
+            const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
+                d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
+            }
+        } else {
+            const V* ip = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
+#pragma unroll
+            for (int k = 0; k < E; ++k) d[k] = ip[(long long)(TY * k) * N2];
+        }
+    };
+    auto store_cols = [&](unsigned plane, unsigned un, const V* v) {
+        if constexpr (ROWS_PRODUCE) {
+            V* op = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
+#pragma unroll
+            for (int k = 0; k < E; ++k) op[(long long)(TY * k) * N2] = v[k];
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
+            }
+        }
+    };
+    auto is_rows = [&](unsigned kind) { return (kind == PROD) == ROWS_PRODUCE; };
+    auto load_unit = [&](const Item& it, V* d) {
+        if (is_rows(it.kind)) load_rows(it.plane, it.unit, d);
+        else load_cols(it.plane, it.unit, d);
+    };
+    auto process_unit = [&](const Item& it, V* v) {
+        if (is_rows(it.kind)) {
+            run_stages<V, PZ, 0, DIR, 1, true, true, TW_REG, TWPOW>(v, twzr, lds_row, jz, 0);
+            store_rows(it.plane, it.unit, v);
+        } else {
+            __syncthreads();  // the LDS rows of an earlier row unit are no longer read
+            run_stages<V, PY, 0, DIR, CB, false, false, TW_REG, TWPOW>(v, twyr, lds, jy, cy);
+            store_cols(it.plane, it.unit, v);
+            __syncthreads();  // the tile is no longer read when the next unit scatters
+        }
+        if (it.kind == PROD) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the unit's results have left this CU
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&ctl->done[it.plane], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+        }
+    };
+
+    V v[E], vn[E];
+    // tickets are taken two items ahead, so that the atomic's round trip overlaps a whole unit of work
+    Item cur = decode(share(take()));
+    Item nxt = decode(share(take()));
+    if (cur.kind != NONE) {
+        if (!ready(cur, true)) return;
+        load_unit(cur, v);
+    }
+    while (cur.ticket < total) {
+        const unsigned t2 = take();
+        bool           loaded = false;
+        if (nxt.kind != NONE && ready(nxt, false)) {  // prefetch only what may be read already
+            load_unit(nxt, vn);
+            loaded = true;
+        }
+        if (cur.kind != NONE) process_unit(cur, v);
+        const Item nn = decode(share(t2));
+        if (nxt.kind != NONE && !loaded) {
+            if (!ready(nxt, true)) return;
+            load_unit(nxt, v);
+        } else if (loaded) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = vn[k];
+        }
+        cur = nxt;
+        nxt = nn;
+    }
+}
+
+template <class PZ, class PY, int DIR> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
+    constexpr int    THREADS = 8 * PY::T, GR = THREADS / PZ::T;
+    constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * 8 * sizeof(double2);
+    constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
+    auto             kern = zy_chunk_kernel<PZ, PY, DIR>;
+    static std::atomic<int> blocks_per_cu[64];
+    static std::mutex       setup_mutex;
+    int                     dev = 0;
+    hipError_t              e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, THREADS, LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
+    }
+    // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing)
+    const long long grid = device_info().cus;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
+                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.nplanes, (unsigned)L.chunk);
+    return hipGetLastError();
+}
+
+using P256 = Plan<256, 8, 8, 8, 4>;
+using P512 = Plan<512, 8, 8, 8, 8>;
+
+}  // namespace
+
+bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512) && (n2 == 256 || n2 == 512); }
+
+hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
+    if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
+#define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                  \
+    if (L.n2 == NZ && L.n1 == NY)                                                      \
+        return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1>(L, stream) : launch_zy_t<PZ_, PY_, -1>(L, stream);
+    DFFT_ZY_CASE(512, 512, P512, P512)
+    DFFT_ZY_CASE(256, 256, P256, P256)
+    DFFT_ZY_CASE(512, 256, P512, P256)
+    DFFT_ZY_CASE(256, 512, P256, P512)
+#undef DFFT_ZY_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dfft

@@ -286,6 +286,43 @@ def test_untimed_executes_back_to_back_are_bit_identical(gpu):
             pl.destroy()
 
 
+@pytest.mark.parametrize("N,chunk", [((16, 256, 256), 5), ((12, 512, 256), 4), ((9, 256, 512), 2), ((70, 512, 512), 64), ((512, 256, 256), 0)])
+def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
+    """t0 as ONE persistent launch (dfft_zy.hip: ticket-ordered row and column units, sc1 hand-off through the hand-over buffer)
+    against the two launches per cache chunk it replaces: bit-identical results in both directions, with several chunks and a
+    ragged last chunk, also when executes are queued back to back; and against the oracle."""
+    import torch
+    from distributedfft_amd import api
+    monkeypatch.setenv("DFFT_PAD", "1")            # small slabs get the hand-over buffer too
+    if chunk:
+        monkeypatch.setenv("DFFT_CHUNK_PLANES", str(chunk))
+    n = N[0] * N[1] * N[2]
+    x = so.random_input(N, seed=N[0] + 3)
+    a = torch.from_numpy(x.reshape(-1)).to(gpu)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", mode)
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+        p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+        q = api.Plan(*N, b, c, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+        for _ in range(3):
+            p.execute(api.EXEC_NO_TIMING)
+        p.execute()
+        p.sync()
+        assert len(p.stage_times()) == 4
+        for _ in range(2):
+            q.execute(api.EXEC_NO_TIMING)
+        q.sync()
+        outs[mode] = (b.clone(), c.clone())
+        p.destroy()
+        q.destroy()
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    ref = so.fftn_reference(x, 1)[0]
+    got = outs["1"][0].cpu().numpy().reshape(ref.shape)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
+    assert (outs["1"][1] / n - a).abs().max().item() < 1e-11
+
+
 def test_plan_tune_keeps_results_bit_identical(gpu):
     """dfft_plan_tune (plan-time placement measurement of the hand-over buffer): a plan that owns such a buffer -- planes a
     multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- probes its candidates with the X-pass kernel alone

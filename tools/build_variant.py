@@ -15,7 +15,7 @@ obj.mkdir(parents=True, exist_ok=True)
 units = [(B.CSRC / "dfft_fft_inst.hip", obj / f"dfft_fft_inst_{g}.o", [f"-DDFFT_INST_GROUP={g}"] + flags) for g in range(B.NUM_INST_GROUPS)]
 with ThreadPoolExecutor(max_workers=8) as ex:
     list(ex.map(lambda u: B._run([B.HIPCC] + B.COMMON + u[2] + ["-c", str(u[0]), "-o", str(u[1])]), units))
-others = [str(B.OBJ / f"{n}.o") for n in ("dfft_kernels", "dfft_generic", "dfft_long", "dfft_plan", "dfft_exchange", "dfft_bootstrap", "dfft_alloc")]
+others = [str(B.OBJ / f"{n}.o") for n in ("dfft_kernels", "dfft_generic", "dfft_long", "dfft_plan", "dfft_exchange", "dfft_bootstrap", "dfft_alloc", "dfft_zy")]
 tl = B._torch_lib_dir()
 out = B.LIBDIR / f"libdfft_variant_{name}.so"
 B._run(["g++", "-shared", "-fPIC", "-o", str(out)] + [str(u[1]) for u in units] + others +
