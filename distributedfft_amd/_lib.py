@@ -56,6 +56,7 @@ SIGNATURES = {
     "dfft_execute": (C.c_int, [_VP, C.c_uint]),
     "dfft_plan_sync": (C.c_int, [_VP]),
     "dfft_plan_tune": (C.c_int, [_VP]),
+    "dfft_plan_describe": (C.c_int, [_VP, C.c_char_p, C.c_int]),
     "dfft_plan_tune_report": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dfft_plan_set_scale": (C.c_int, [_VP, C.c_double]),
     "dfft_stage_times": (C.c_int, [_VP, C.POINTER(C.c_double)]),

@@ -224,6 +224,12 @@ class Plan:
         with torch.cuda.device(self.device):
             L.check(L.load().dfft_plan_tune(self.handle), "dfft_plan_tune")
 
+    def describe(self) -> str:
+        """How this plan executes (dfft_plan_describe): pipeline, YZ stage form, chunk geometry, hand-over buffer, rotation."""
+        buf = C.create_string_buffer(512)
+        L.check(L.load().dfft_plan_describe(self.handle, buf, 512), "dfft_plan_describe")
+        return buf.value.decode()
+
     def tune_report(self) -> dict:
         """{'candidates_ms': [...], 'kept': i, 'kept_retimed_ms': t} of the last tune() (dfft_plan_tune_report)."""
         ms = (C.c_double * 16)()

@@ -549,7 +549,10 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 #ifndef DFFT_HALF_PREFETCH
 #define DFFT_HALF_PREFETCH 1
 #endif
-    constexpr int PF = PREFETCH ? E : (DFFT_HALF_PREFETCH && Tune::PREFETCH && E == 16 && sizeof(V) == 16 && KG::THREADS <= 512 && KG::PH == 1 ? E / 2 : 0);
+    // (only the staged-store variant -- the X pass -- has the registers: 192 -> 228; the plain column variants sit at 216 and would
+    // spill 28-68 B with it.  Measured: 1024-point X pass on fp32 column pairs 4.5 -> 4.9 TB/s, fp64 unchanged at 4.6-4.7;
+    // profiles/r03/experiments/half_prefetch_ab.log)
+    constexpr int PF = PREFETCH ? E : (DFFT_HALF_PREFETCH && Tune::PREFETCH && KG::OSTAGE && E == 16 && sizeof(V) == 16 && KG::THREADS <= 512 && KG::PH == 1 ? E / 2 : 0);
     constexpr bool PARTIAL = PF > 0 && PF < E;
     using K0 = std::integral_constant<int, 0>;
     using KP = std::integral_constant<int, PF>;

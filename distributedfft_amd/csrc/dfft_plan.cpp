@@ -228,6 +228,7 @@ struct dfft_plan_s {
     // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
     ZyCtl*                  zy_ctl = nullptr;
     bool                    zy_on = false;
+    unsigned                zy_gen = 0;  // launches the control block has served
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.
     int                     rot_elems = 0;
@@ -452,7 +453,7 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* dst) {
     L.ctl = p->zy_ctl;
     L.twz = twz;
     L.twy = twy;
-    DFFT_HIP_TRY(hipMemsetAsync(p->zy_ctl, 0, 256 + sizeof(unsigned) * (size_t)p->xs, p->stream));
+    L.generation = p->zy_gen++;  // the control block's counters run on from launch to launch (no reset between transforms)
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
 }
 
@@ -1127,8 +1128,14 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         if (!(oe && *oe == '0') && p->wbuf && !p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && p->wl.pitch == n2 &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
-            if (hipMalloc((void**)&p->zy_ctl, sizeof(ZyCtl)) == hipSuccess) p->zy_on = true;
-            else (void)hipGetLastError();
+            // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
+            // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test
+            // suite, on recycled memory)
+            if (hipMalloc((void**)&p->zy_ctl, sizeof(ZyCtl)) == hipSuccess && hipMemsetAsync(p->zy_ctl, 0, sizeof(ZyCtl), p->stream) == hipSuccess &&
+                hipStreamSynchronize(p->stream) == hipSuccess)
+                p->zy_on = true;
+            else
+                (void)hipGetLastError();
         }
     }
     if (p->long_axis) {
@@ -1353,6 +1360,20 @@ int dfft_plan_tune(dfft_plan_t plan) {
         fprintf(stderr, " ms, kept candidate %d (%.4f ms when re-timed)\n", p->w_kept, p->w_final_ms);
     }
     return rc;
+}
+
+int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
+    if (!plan || !buf || len < 64) return fail(DFFT_EINVAL, "dfft_plan_describe: bad arguments");
+    const dfft_plan_s* p = plan;
+    const long long    cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
+    const long long    nch = cp > 0 ? (p->xs + cp - 1) / cp : 1;
+    const bool         fused = !(p->flags & DFFT_PLAN_UNFUSED);
+    snprintf(buf, (size_t)len,
+             "pipeline=%s yz_stage=%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d",
+             (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
+             (p->zy_on && fused && !p->exch && p->wbuf) ? "one-launch" : "two-launches-per-chunk", nch, cp,
+             (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0);
+    return DFFT_OK;
 }
 
 int dfft_plan_tune_report(dfft_plan_t plan, int max_n, double* ms, int* kept, double* final_ms) {

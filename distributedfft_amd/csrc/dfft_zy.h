@@ -6,7 +6,7 @@ namespace dfft {
 
 enum { ZY_MAX_PLANES = 4096 };
 
-// control block in device memory, zeroed on the plan's stream before every launch
+// control block in device memory, zeroed once when the plan is created (launches count on from where the last one stopped)
 struct alignas(128) ZyCtl {
     unsigned ticket;               // next work item
     unsigned pad0[31];
@@ -25,6 +25,7 @@ struct ZyLaunch {
     long long   src_plane, w_plane, dst_plane;
     long long   nplanes, chunk;  // planes; planes per Infinity-Cache phase
     ZyCtl*      ctl;
+    unsigned    generation;  // how many launches this control block has served (all with the same geometry and direction)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
 };
 

@@ -35,7 +35,8 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 template <class PZ, class PY, int DIR>
 __global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
-                long long src_plane, long long w_plane, long long dst_plane, unsigned nplanes, unsigned chunk) {
+                long long src_plane, long long w_plane, long long dst_plane, unsigned nplanes, unsigned chunk, unsigned ticket_base,
+                unsigned done_base) {
     using V = double2;
     constexpr int CB = 8;  // column tiles of one cache line
     constexpr int THREADS = CB * PY::T;
@@ -66,7 +67,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 
     const unsigned CH = chunk;
     const unsigned nchunks = (nplanes + CH - 1) / CH;
-    const unsigned total = nchunks * CH * BB;  // tickets (some of the last chunk's are empty)
+    const unsigned total = nchunks * CH * BB;  // tickets (some of the last chunk's are empty); the host's ticket_base steps by this
     enum { NONE = 0, PROD = 1, CONS = 2 };
     struct Item {
         unsigned ticket, kind, plane, unit;
@@ -92,18 +93,20 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         return t;
     };
     auto take = [&]() -> unsigned {  // thread 0: the next ticket (the atomic's latency hides behind the caller's work)
-        return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) : 0u;
+        // (the counters are never reset: launch g of a plan starts at ticket_base = g * total and done_base = g * UA, all in
+        // wrapping 32-bit arithmetic, so no memset launch sits between two transforms)
+        return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - ticket_base : 0u;
     };
     // dependency of a consumer unit: every producer unit of its plane has published.  wait = false: one poll only.
     auto ready = [&](const Item& it, bool wait) -> bool {
         if (it.kind != CONS) return true;
         if (tid == 0) {
-            unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) >= UA ? 1u : 0u;
+            unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA ? 1u : 0u;
             if (!ok && wait) {
                 const unsigned long long t0 = wall_clock64();
                 for (;;) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) >= UA) {
+                    if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA) {
                         ok = 1u;
                         break;
                     }
@@ -259,8 +262,16 @@ template <class PZ, class PY, int DIR> hipError_t launch_zy_t(const ZyLaunch& L,
     // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing)
     const long long grid = device_info().cus;
     (void)hipGetLastError();
+    // every workgroup takes tickets until it sees one past the end: the counter advances by total + overshoot per launch, where the
+    // overshoot is exactly 2 per workgroup (two tickets are held ahead) -- the same count every time, so the next launch's base is known
+    constexpr unsigned UZ = PY::N / GR, UY = PZ::N / 8, BB = UZ + UY, UA = DIR > 0 ? UZ : UY;
+    const unsigned     nchunks = (unsigned)((L.nplanes + L.chunk - 1) / L.chunk);
+    const unsigned     total = nchunks * (unsigned)L.chunk * BB;
+    const unsigned     per_launch = total + 2u * (unsigned)grid;
+    const unsigned     ticket_base = (unsigned)L.generation * per_launch, done_base = (unsigned)L.generation * UA;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
-                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.nplanes, (unsigned)L.chunk);
+                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.nplanes, (unsigned)L.chunk,
+                       ticket_base, done_base);
     return hipGetLastError();
 }
 

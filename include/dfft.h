@@ -172,6 +172,11 @@ int dfft_plan_sync(dfft_plan_t plan);
  * bit-identical with and without tuning.  The reference-named wrapper fft_mpi_plan_dft_c2c_3d, distFFTOpt, speed3d_c2c and
  * bench.py all call it for out-of-place plans, so the drop-in CLI times the same configuration as the benchmark. */
 int dfft_plan_tune(dfft_plan_t plan);
+/* One line of text about how this plan executes: pipeline (fused / unfused / natural), whether the YZ stage is one persistent
+ * launch or two launches per cache chunk, the chunk geometry, where the intermediate lives, whether the exchange buffers' rows
+ * are rotated, the overlap geometry, and whether dfft_plan_tune has placed the hand-over buffer.  Diagnostics (bench.py puts it
+ * in its JSON line); no counterpart in the reference.  buf must hold at least 64 bytes. */
+int dfft_plan_describe(dfft_plan_t plan, char* buf, int len);
 /* What the last dfft_plan_tune of this plan saw: ms[i] = X-pass kernel time on candidate i (at most max_n are written), *kept =
  * index of the candidate the plan now uses (-1: never tuned), *final_ms = the kept candidate re-timed after the others were
  * freed.  Returns the number of candidates tried.  Any output pointer may be NULL. */

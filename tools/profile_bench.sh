@@ -1,10 +1,10 @@
 #!/bin/bash
-# Profiling recipe of the graded bench line (run on the GPU box through gpurun):  tools/profile_bench.sh [round, default r02]
+# Profiling recipe of the graded bench line (run on the GPU box through gpurun):  tools/profile_bench.sh [round, default r03]
 # Kernel trace + stats and the HBM PMC counters are collected in SEPARATE passes (gpurun refuses --pmc combined with runtime
 # traces; FETCH_SIZE and WRITE_SIZE do not fit in one pass anyway: MI355X_MICROARCH.md "rocprofv3 PMC slots").  The raw
 # output stays under gpurun_out/prof_<round>/ (scratch); tools/summarize_profile.py condenses it into profiles/<round>/ and
 # profiles/hbm_traffic.json, stamped with the sha256 of the library that was profiled.
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/prof_$ROUND; mkdir -p $OUT

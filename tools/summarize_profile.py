@@ -5,7 +5,7 @@
   profiles/<round>/bench_512_fp64_P1_pmc_summary.csv           FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
   profiles/hbm_traffic.json                                    fabric bytes per X-pass launch and per t0 stage for bench.py's
                                                                roofline.traffic, with the sha256 of the profiled library
-usage: python tools/summarize_profile.py [raw dir, default gpurun_out/prof_r02] [round, default r02]
+usage: python tools/summarize_profile.py [raw dir, default gpurun_out/prof_<round>] [round, default r03]
 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section: on gfx950 it reports half of the bytes of a wide coalesced streaming
 read -- 128-byte requests tallied at 64 B); both counters are reported in KB and converted with x1024.  They sit on the L2's
 fabric side, so Infinity-Cache hits are included."""
@@ -18,7 +18,7 @@ from collections import defaultdict
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-ROUND = sys.argv[2] if len(sys.argv) > 2 else "r02"
+ROUND = sys.argv[2] if len(sys.argv) > 2 else "r03"
 SRC = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "gpurun_out" / f"prof_{ROUND}"
 if not SRC.is_absolute():
     SRC = ROOT / SRC
@@ -27,6 +27,9 @@ DST = ROOT / "profiles" / ROUND
 
 def short(name: str) -> str:
     m = re.search(r"fft_tiles_kernel<(.*?), dfft::Plan<(\d+), (\d+)[^>]*>, (\d+), (\d+), (-?\d+), (true|false), dfft::(\w+)>", name)
+    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)>", name)
+    if mz:  # t0 as one persistent launch (dfft_zy.hip)
+        return f"zy_chunk_kernel f64 NZ={mz.group(1)} NY={mz.group(2)} dir={mz.group(3)} (one-launch YZ stage)"
     if not m:
         m2 = re.search(r"fft_generic_kernel<(.*?), (-?\d+)>", name)
         if m2:
@@ -85,7 +88,8 @@ def pmc():
         tot, nexec = 0.0, None
         xn = max([r[-2] for r in out if r[0] == run and "TuneTransposedStore" in r[1]], default=0)  # X launches = executes
         for r in out:
-            if r[0] != run or "N=512" not in r[1] or "dir=1" not in r[1] or "TuneTransposedStore" in r[1]:
+            zy = r[1].startswith("zy_chunk_kernel") and "dir=1" in r[1]
+            if r[0] != run or ((("N=512" not in r[1]) or ("dir=1" not in r[1]) or ("TuneTransposedStore" in r[1])) and not zy):
                 continue
             if xn:
                 tot += r[-1] * r[-2] / xn
