@@ -40,7 +40,8 @@ template <int N_, int E_, int... Rs> struct Plan {
     static_assert(N_ % E_ == 0, "E must divide N");
 };
 
-// Kernel tuning policy (compile time).  The defaults are what the library ships; tools/kbench.hip instantiates others.
+// Kernel tuning policy (compile time).  The defaults are what the library ships; the A/B harnesses of rounds 1-2 (removed; logs under
+// profiles/r01/experiments, profiles/r02/experiments) instantiated others.
 struct TuneDefault {
     static constexpr bool TWPOW = true;    // keep w^1, w^2, w^4 per butterfly, derive the other powers by products
     static constexpr bool OSTAGE = false;  // column kernel: stage results through LDS so every wave stores 1 KiB runs
@@ -63,7 +64,7 @@ template <class Base, int RIN, int ROUT> struct WithRot : Base {
 };
 
 // Column kernel whose store side is the transposed one ([..][z][kx], kx fastest: the forward X pass).  Measured on
-// MI355X at 512^3 fp64 (tools/kbench, profiles/): direct 128-byte-segment stores 1.20 ms; results staged through LDS so
+// MI355X at 512^3 fp64 (profiles/r01/experiments): direct 128-byte-segment stores 1.20 ms; results staged through LDS so
 // each wave stores 1 KiB runs + two resident blocks per CU (<= 128 VGPRs) + streaming (non-temporal) access 0.92 ms.
 // Adding a register prefetch of the next tile (the block then overlaps HBM latency with its own barriers) beats holding
 // the kernel to 128 VGPRs for a second resident block: 0.95 -> 0.90 ms.
@@ -122,7 +123,7 @@ constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 
 
 // When T is a multiple of Ns all B butterflies of a thread's stage share one twiddle set ((j + q*T) mod Ns does not depend on
 // q), so only SLOTS registers are needed for that stage.  Counting this way would move N = 100, 1024 and 2048 from the LDS / L2
-// table to registers; measured (tools/kbench8.hip, round 1) that costs 3-6 % on the 1024/2048-point column kernels (register
+// table to registers; measured (round 1, profiles/r01/experiments) that costs 3-6 % on the 1024/2048-point column kernels (register
 // pressure), so the sharing is switched on only for 4096 points, where 16 points x 256 threads then keep 12 twiddles in
 // registers instead of a 64 KiB LDS table that, next to the 72 KiB row tile, would leave one workgroup per CU.
 #ifndef DFFT_TW_EFFECTIVE
@@ -253,7 +254,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
     }
     if constexpr (S + 1 < P::S) {
 #ifdef DFFT_DBG_NOEXCH
-        // measurement builds only (tools/kbench): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
+        // measurement builds only (-DDFFT_DBG_NOEXCH): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
         run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
         return;
 #endif
@@ -383,7 +384,7 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
 }
 
 // register prefetch only where the second register set is cheap (64 VGPRs, i.e. E = 16 fp64: 1024-point columns
-// 4.6 -> 3.7 TB/s, tools/kbench8.hip)
+// 4.6 -> 3.7 TB/s, round 1)
 #ifndef DFFT_PREFETCH_MAX_REGS
 #define DFFT_PREFETCH_MAX_REGS 32
 #endif
@@ -1032,7 +1033,7 @@ template <class V, class P> constexpr int cols_per_tile() {
 }
 
 // staging the transposed store pays when the tile rows are full 128-byte lines and the image fits the LDS
-// (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; tools/kbench5.hip)
+// (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; round 1)
 template <class V, class P> constexpr bool can_stage_store() {
     constexpr int CBC = cols_per_tile<V, P>();
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;

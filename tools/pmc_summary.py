@@ -24,5 +24,5 @@ for f in sorted(glob.glob(src + "/pass_*/**/*counter_collection.csv", recursive=
     print("group," + ",".join(names))
     for g in range(0, len(ids), group):
         chunk = [per[i] for i in ids[g:g + group]]
-        tail = chunk[len(chunk) // 2:]  # second half of the group: steady state
+        tail = chunk[len(chunk) // 2:] if group < 100000 else chunk  # per-plan groups: second half = steady state
         print("%d," % (g // group) + ",".join("%.6g" % (sum(d.get(n, 0.0) for d in tail) / len(tail)) for n in names))

@@ -91,7 +91,9 @@ def pmc():
             zy = r[1].startswith("zy_chunk_kernel") and "dir=1" in r[1]
             if r[0] != run or ((("N=512" not in r[1]) or ("dir=1" not in r[1]) or ("TuneTransposedStore" in r[1])) and not zy):
                 continue
-            if xn:
+            if zy:
+                tot += r[-1]            # one launch per execute: the mean per dispatch IS the stage's traffic
+            elif xn:
                 tot += r[-1] * r[-2] / xn
         return tot if xn else None
     if fetch and write:
@@ -112,8 +114,9 @@ def pmc():
             ent["t0 chunk kernels (Z rows + Y columns)"] = {
                 "FETCH_SIZE_KB": round(f0, 1), "WRITE_SIZE_KB": round(w0, 1), "hbm_bytes_per_launch": (2 * f0 + w0) * 1024,
                 "algorithmic_bytes_per_launch": 2 * 16 * 512 ** 3,
-                "note": "sum over all chunk launches of one execute; the Z -> Y intermediate crosses the fabric twice (written to "
-                        "and read back from the Infinity Cache), hence ~2x the algorithmic bytes of the stage"}
+                "note": "the whole t0 stage of one execute (one persistent launch, or the sum over its chunk launches); the Z -> Y "
+                        "intermediate crosses the fabric twice (written to and read back from the Infinity Cache), hence ~2x the "
+                        "algorithmic bytes of the stage"}
         (ROOT / "profiles" / "hbm_traffic.json").write_text(json.dumps({"512x512x512_fp64_P1": ent}, indent=1) + "\n")
         print("X pass: traffic", traffic, "= %.4f x algorithmic" % (traffic / (2 * 16 * 512 ** 3)))
         if f0 and w0:
