@@ -9,11 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/prof_$ROUND; mkdir -p $OUT
 sha256sum $R/distributedfft_amd/lib/libdfft_mi355x_pt.so | cut -d' ' -f1 > $OUT/library_sha256.txt
-BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_default -- $BENCH > $OUT/trace_default.log 2>&1
 # PROFILE_SKIP_NOCHUNK=1: only the default (chunked) configuration -- three passes instead of six
 [ -z "$PROFILE_SKIP_NOCHUNK" ] && DFFT_CHUNK_MB=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nochunk -- $BENCH > $OUT/trace_nochunk.log 2>&1
-BENCH2="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH2="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_default -- $BENCH2 > $OUT/pmc_fetch_default.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_default -- $BENCH2 > $OUT/pmc_write_default.log 2>&1
 [ -z "$PROFILE_SKIP_NOCHUNK" ] && DFFT_CHUNK_MB=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_nochunk -- $BENCH2 > $OUT/pmc_fetch_nochunk.log 2>&1

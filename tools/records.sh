@@ -11,7 +11,7 @@ cd $R
 PROFILE_SKIP_NOCHUNK=1 bash tools/profile_bench.sh $ROUND > $OUT/profile_bench.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 P=$R/gpurun_out/prof_$ROUND
-BENCH2="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH2="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $P/pass_sq -- $BENCH2 > $P/pass_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_LEVEL_sum --output-format csv -d $P/pass_ea -- $BENCH2 > $P/pass_ea.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum --output-format csv -d $P/pass_tcp -- $BENCH2 > $P/pass_tcp.log 2>&1
