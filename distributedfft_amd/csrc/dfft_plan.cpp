@@ -1099,31 +1099,6 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (possible && !(re && *re == '0') && (pays || (re && *re == '1'))) p->rot_elems = (int)(3 * 128 / S);
     }
     {
-        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of NATURAL planes that
-        // fits, evened out over the chunks -- 8 x 64 planes at 512^3 fp64.  With the padded work buffer such a chunk is a few
-        // KiB larger than the cache; measured (profiles/r02/experiments/chunk_planes_sweep.log, two boxes) that is still the
-        // best size: t0 1.37-1.38 ms against 1.40-1.42 for 9 x 57 (sized on the padded planes), 60 or 63 planes, and the X pass
-        // runs no slower behind it.  t0 follows the chunk count (~9 us per Z+Y launch pair) and is worst just above a
-        // power-of-two size (40 planes: 1.63 ms); chunks of whole grid-stride rounds (56 / 60 planes) gain nothing.
-        // Planes of 8 MiB and more (1024-point Y columns) keep one plane of head-room: 1024^3 15 instead of 16 planes t0 12.6 ->
-        // 12.4 ms, 2048 x 1024 x 512 31 instead of 32 planes 12.5 -> 12.1 ms; smaller planes want the full count (512^3 fp64 64
-        // planes, fp32 128 planes 0.80 -> 0.74 ms, 384^3 4 x 96; profiles/r02/experiments/chunk_shapes.log).
-        // DFFT_CHUNK_MB=0 disables, =k overrides the capacity; DFFT_CHUNK_PLANES=n sets the chunk size directly (experiments).
-        long long   mb = 256;
-        const char* ce = getenv("DFFT_CHUNK_MB");
-        if (ce) mb = atoll(ce);
-        if (mb > 0) {
-            const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
-            long long       fit = std::max(1ll, (mb << 20) / plane_b);
-            if (plane_b >= (8ll << 20) && fit > 1) --fit;
-            const long long nchunks = (p->xs + fit - 1) / fit;
-            p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
-        }
-        const char* cpe = getenv("DFFT_CHUNK_PLANES");
-        if (cpe && atoll(cpe) > 0) p->chunk_planes = atoll(cpe);
-        if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
-    }
-    {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         if (!(oe && *oe == '0') && p->wbuf && !p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && p->wl.pitch == n2 &&
@@ -1137,6 +1112,35 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             else
                 (void)hipGetLastError();
         }
+    }
+    {
+        // Z+Y blocking for the 256 MiB Infinity Cache (MI355X_MICROARCH.md): the largest whole number of NATURAL planes that
+        // fits, evened out over the chunks -- 8 x 64 planes at 512^3 fp64.  With the padded work buffer such a chunk is a few
+        // KiB larger than the cache; measured (profiles/r02/experiments/chunk_planes_sweep.log, two boxes) that is still the
+        // best size: t0 1.37-1.38 ms against 1.40-1.42 for 9 x 57 (sized on the padded planes), 60 or 63 planes, and the X pass
+        // runs no slower behind it.  t0 follows the chunk count (~9 us per Z+Y launch pair) and is worst just above a
+        // power-of-two size (40 planes: 1.63 ms); chunks of whole grid-stride rounds (56 / 60 planes) gain nothing.
+        // Planes of 8 MiB and more (1024-point Y columns) keep one plane of head-room: 1024^3 15 instead of 16 planes t0 12.6 ->
+        // 12.4 ms, 2048 x 1024 x 512 31 instead of 32 planes 12.5 -> 12.1 ms; smaller planes want the full count (512^3 fp64 64
+        // planes, fp32 128 planes 0.80 -> 0.74 ms, 384^3 4 x 96; profiles/r02/experiments/chunk_shapes.log).
+        // DFFT_CHUNK_MB=0 disables, =k overrides the capacity; DFFT_CHUNK_PLANES=n sets the chunk size directly (experiments).
+        // The one-launch stage (dfft_zy.hip) has no launch boundaries to amortise and wants head-room instead: 9 phases of 57 planes
+        // (228 MiB) run t0 of 512^3 fp64 in 1.213-1.216 ms, 8 x 64 (256 MiB + padding) in 1.297, 10 x 52 in 1.238, and any
+        // count that leaves a short last phase loses (56 -> 9 x 56 + 8: 1.284; 62: 1.341; profiles/r03/experiments/
+        // chunk_planes_one_launch.log) -- so: 230 MiB, evened out over the phases as before.
+        long long   mb = p->zy_on ? 230 : 256;
+        const char* ce = getenv("DFFT_CHUNK_MB");
+        if (ce) mb = atoll(ce);
+        if (mb > 0) {
+            const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
+            long long       fit = std::max(1ll, (mb << 20) / plane_b);
+            if (plane_b >= (8ll << 20) && fit > 1) --fit;
+            const long long nchunks = (p->xs + fit - 1) / fit;
+            p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
+        }
+        const char* cpe = getenv("DFFT_CHUNK_PLANES");
+        if (cpe && atoll(cpe) > 0) p->chunk_planes = atoll(cpe);
+        if (p->chunk_planes >= p->xs) p->chunk_planes = 0;
     }
     if (p->long_axis) {
         p->chunk_planes = 0;  // the four-step passes work on the whole slab
@@ -1247,10 +1251,11 @@ int dfft_plan_tune(dfft_plan_t plan) {
     // Candidates: the current buffer, then fresh allocations with a spacer in front of each.  The regions that matter are tens
     // of GiB long (one 128 GiB allocation is half and half; tools/xprobe.hip, profiles/r03/experiments/xprobe_*.log) and the
     // driver hands out device memory top-down, so a spacer that stays allocated moves the next candidate that far on.  The
-    // spacers grow -- 8, 8, 16, 32, 64 GiB -- so that six candidates reach 130 GiB; bounded by DFFT_TUNE_TRIES (default 6) and
-    // by what is free (the transient footprint never exceeds 60 % of the free device memory).  DFFT_TUNE_SPACER_MB fixes the
+    // spacers grow -- 8, 8, 16, 32, 64, 32 GiB -- so that seven candidates reach 170 GiB, more than half of the device (some processes
+    // see no change of behaviour over 130 GiB: profiles/r03/experiments/tune_check_*.log); bounded by DFFT_TUNE_TRIES (default 7)
+    // and by what is free (the transient footprint never exceeds 70 % of the free device memory).  DFFT_TUNE_SPACER_MB fixes the
     // spacer size instead.
-    int         max_tries = 6;
+    int         max_tries = 7;
     const char* mt = getenv("DFFT_TUNE_TRIES");
     if (mt && atoi(mt) > 0) max_tries = atoi(mt);
     long long   fixed_spacer = -1;
@@ -1258,15 +1263,15 @@ int dfft_plan_tune(dfft_plan_t plan) {
     if (sm && atoll(sm) >= 0) fixed_spacer = atoll(sm) << 20;
     auto spacer_for = [&](int k) -> size_t {  // spacer in front of candidate k (k >= 1)
         if (fixed_spacer >= 0) return (size_t)fixed_spacer;
-        static const int gib[] = {8, 8, 16, 32, 64};
-        return (size_t)gib[std::min(k - 1, 4)] << 30;
+        static const int gib[] = {8, 8, 16, 32, 64, 32};
+        return (size_t)gib[std::min(k - 1, 5)] << 30;
     };
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
         free_b = 0;
     }
-    const size_t budget = free_b / 10 * 6;
+    const size_t budget = free_b / 10 * 7;
     std::vector<void*> cand(1, p->wbuf), spacers;
     p->w_ms.clear();
     float ms = 0.f;
