@@ -228,7 +228,8 @@ struct dfft_plan_s {
     // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
     ZyCtl*                  zy_ctl = nullptr;
     bool                    zy_on = false;
-    unsigned                zy_gen = 0;  // launches the control block has served
+    unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
+    unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.
     int                     rot_elems = 0;
@@ -276,6 +277,23 @@ static int fill_exchange(dfft_plan_s* p, ExchangeDesc& x, int direction) {
     return DFFT_OK;
 }
 
+// The packed side of the Y pass: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even X and Y splits only) [k][d][xs][yl/ycuts][N2]:
+// sub-block k of the send buffer is exactly the region the X pass of sub-block k overwrites with its result, so a result never
+// lands on send data that is still in flight (execute_forward).  tile->a_stride = distance between consecutive X planes in a block.
+static void packed_map(const dfft_plan_s* p, AxisMap* packed, TileMap* tile) {
+    const long long n2 = p->N[2];
+    const long long ysub = p->sy.blk / p->ycuts;
+    packed->blk = (int)ysub;
+    packed->nblk = p->P * p->ycuts;
+    packed->blk_stride = p->xs * ysub * n2;
+    packed->sub = p->ycuts;
+    packed->sub_stride = (long long)p->P * p->xs * ysub * n2;
+    packed->stride = n2;
+    packed->cstride = 1;
+    packed->last_delta = p->ycuts > 1 ? 0 : (p->sy.size(p->P - 1) - p->sy.blk) * n2;
+    *tile = TileMap{ysub * n2, 1};
+}
+
 // Y pass.  Natural side: [xs][N1][N2].  Packed side: [d][xs][yl_d][N2].
 // lay_in / lay_out: layout of the natural side(s) (nullptr = {N2, N1*N2}); ignored for a packed side.
 static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_is_out, bool use_packed, long long x0,
@@ -302,20 +320,9 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
     L.tw = tw;
     const SlabLayout nat{n2, (long long)n1 * n2};
     const SlabLayout li = lay_in ? *lay_in : nat, lo = lay_out ? *lay_out : nat;
-    // packed side: [d][xs][yl_d][N2]; with Y sub-blocks (ycuts > 1, even X and Y splits only) [k][d][xs][yl/ycuts][N2]:
-    // sub-block k of the send buffer is exactly the region the X pass of sub-block k overwrites with its result, so a
-    // result never lands on send data that is still in flight (execute_forward)
-    const long long ysub = p->sy.blk / p->ycuts;
     AxisMap packed;
-    packed.blk = (int)ysub;
-    packed.nblk = p->P * p->ycuts;
-    packed.blk_stride = p->xs * ysub * n2;
-    packed.sub = p->ycuts;
-    packed.sub_stride = (long long)p->P * p->xs * ysub * n2;
-    packed.stride = n2;
-    packed.cstride = 1;
-    packed.last_delta = p->ycuts > 1 ? 0 : (p->sy.size(p->P - 1) - p->sy.blk) * n2;
-    TileMap pk_tile{ysub * n2, 1};
+    TileMap pk_tile;
+    packed_map(p, &packed, &pk_tile);
     L.imap = plain_axis(n1, li.pitch, 1);
     L.itile = TileMap{li.plane, 1};
     L.omap = plain_axis(n1, lo.pitch, 1);
@@ -432,8 +439,27 @@ struct StageClock {
         if (rc_) return rc_;  \
     } while (0)
 
-// t0 of a single-GPU fused plan as one launch: forward src -> wbuf (Z) -> wbuf (Y); backward wbuf (Y) -> dst (Z)
-static int launch_zy_stage(dfft_plan_s* p, const void* src, void* dst) {
+// Planes per phase of the one-launch YZ stage for a slab (or part) of nx planes: one that fits the 256 MiB Infinity Cache is ONE
+// phase; larger ones are cut into equal phases of at most 230 MiB -- head-room instead of the largest possible size, see
+// dfft_plan_create; a short last phase costs more than it saves.  DFFT_CHUNK_PLANES overrides.
+static long long zy_phase_planes(const dfft_plan_s* p, long long nx) {
+    static const long long forced = [] {
+        const char* e = getenv("DFFT_CHUNK_PLANES");
+        return e ? atoll(e) : 0ll;
+    }();
+    const long long plane_b = p->N[1] * p->N[2] * (long long)elem_bytes(p->dtype);
+    if (forced > 0) return std::min(forced, nx);
+    if (nx * plane_b <= (256ll << 20)) return nx;
+    const long long fit = std::max(1ll, (230ll << 20) / plane_b), nch = (nx + fit - 1) / fit;
+    return (nx + nch - 1) / nch;
+}
+
+// t0 (or its inverse) of planes [x0, x0 + nx) as one launch (dfft_zy.hip).
+//   forward : Z rows src -> w, Y columns w -> w in place, or (packed) w -> the packed send layout in `other`
+//   backward: Y columns w -> w in place, or (packed) the packed receive layout in `other` -> w; then Z rows w -> dst
+static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w_plane, void* dst, void* other, bool packed, long long x0,
+                           long long nx) {
+    if (nx <= 0) return DFFT_OK;
     const void *twz = nullptr, *twy = nullptr;
     DFFT_TRY(get_twiddles((int)p->N[2], p->dtype, &twz));
     DFFT_TRY(get_twiddles((int)p->N[1], p->dtype, &twy));
@@ -444,16 +470,37 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* dst) {
     L.n2 = (int)p->N[2];
     L.dir = p->direction;
     L.src = src;
-    L.w = p->wbuf;
+    L.w = w;
     L.dst = dst;
     L.src_plane = L.dst_plane = p->N[1] * p->N[2];
-    L.w_plane = p->wl.plane;
-    L.nplanes = p->xs;
-    L.chunk = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
+    L.w_plane = w_plane;
+    L.plane0 = x0;
+    L.nplanes = nx;
+    L.chunk = zy_phase_planes(p, nx);
     L.ctl = p->zy_ctl;
     L.twz = twz;
     L.twy = twy;
-    L.generation = p->zy_gen++;  // the control block's counters run on from launch to launch (no reset between transforms)
+    if (packed) {
+        TileMap tile;
+        packed_map(p, &L.pk, &tile);
+        L.packed = 1;
+        L.pk_plane = tile.a_stride;
+        if (p->direction == DFFT_FORWARD) L.dst = other;
+        else L.src = other;
+        if (p->rot_elems > 0) {
+            L.rot.rot = p->rot_elems;
+            L.rot.mask = (int)p->N[2] - 1;
+            L.rot.a0 = (int)p->sx.start(p->me);
+        }
+    }
+    // the control block's counters run on from launch to launch (no reset between transforms): the ticket counter by what every
+    // launch consumes, the per-plane counters by the producers of one plane per execute
+    unsigned producers = 0;
+    (void)zy_units_per_plane(L.n1, L.n2, L.dir, &producers);
+    if (x0 == 0) p->zy_cur = p->zy_execs++;
+    L.ticket_base = p->zy_ticket;
+    L.done_base = p->zy_cur * producers;
+    p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.nplanes, L.chunk);
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
 }
 
@@ -493,7 +540,9 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         for (int k = 0; k < K; ++k) {
             long long x0, nx;
             part_range(p->xs, p->part_planes, k, &x0, &nx);
-            if (nx > 0) {
+            if (nx > 0 && p->zy_on) {  // Z rows + packing Y columns of the part in one launch
+                DFFT_TRY(launch_zy_stage(p, zsrc, zdst, zl.plane, nullptr, p->buf2, true, x0, nx));
+            } else if (nx > 0) {
                 DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
                                   zsrc != zdst ? FFT_HINT_STREAM_IN : 0, 1.0, lnat, lz, lz ? n1 : 0));
                 DFFT_TRY(launch_y(p, zdst, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT, &zl));
@@ -538,9 +587,9 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    const bool      one_launch = p->zy_on && fused && !y_packs && p->wbuf && zdst == p->wbuf;
-    if (one_launch) {  // the same chunk phases inside ONE persistent launch (dfft_zy.hip)
-        DFFT_TRY(launch_zy_stage(p, zsrc, nullptr));
+    const bool      one_launch = p->zy_on && fused;
+    if (one_launch) {  // the same chunk phases inside ONE persistent launch (dfft_zy.hip); P > 1: the Y side packs into the send buffer
+        DFFT_TRY(launch_zy_stage(p, zsrc, zdst, zl.plane, nullptr, y_packs ? p->buf2 : nullptr, y_packs, 0, p->xs));
     }
     for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {
         const long long nx = std::min(cp, p->xs - x0);
@@ -664,7 +713,9 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
             }
             long long x0, nx;
             part_range(p->xs, p->part_planes, i, &x0, &nx);
-            if (nx > 0) {
+            if (nx > 0 && p->zy_on) {  // unpacking Y columns + Z rows of the part in one launch
+                DFFT_TRY(launch_zy_stage(p, nullptr, ydst, yl.plane, p->buf2, p->buf1, true, x0, nx));
+            } else if (nx > 0) {
                 DFFT_TRY(launch_y(p, p->buf1, ydst, false, true, x0, nx, FFT_HINT_STREAM_IN, nullptr, &yl));
                 DFFT_TRY(fft_rows(ydst, p->buf2, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1, 0, 1.0, ly, lnat, ly ? n1 : 0));
             }
@@ -705,8 +756,9 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     const long long cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
     // streaming hints whenever the stage works on cache-sized pieces of a slab too big to be cache-resident as a whole
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
-    const bool one_launch = p->zy_on && xw && ydst == p->wbuf;
-    if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, ybuf));  // Y columns in place, then Z rows into the result: one launch
+    const bool one_launch = p->zy_on && fused;
+    // Y columns (in place on the intermediate, or unpacking the receive buffer into it), then Z rows into the result: one launch
+    if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, fused ? ydst : ybuf, yl.plane, ybuf, y_unpacks ? p->buf1 : nullptr, y_unpacks, 0, p->xs));
     for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
@@ -1101,7 +1153,15 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
-        if (!(oe && *oe == '0') && p->wbuf && !p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && p->wl.pitch == n2 &&
+        const long long ysub = p->sy.blk / std::max(1, p->ycuts);
+        const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2);
+        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && ysub % (n1 / 8) == 0;  // even splits; a
+                                   // destination block is a whole number of the column unit's 8-point-per-thread strides
+        // P > 1 plans only on request (DFFT_T0_ONE_LAUNCH=all): measured per rank at 512^3 fp64 the packed form gains nothing over two
+        // launches per chunk (P = 4: 0.339 vs 0.338 ms; profiles/r03/experiments/local_by_P_one_launch.log) -- the Y units then
+        // stream their results to HBM instead of working in the cache, and a part of the overlapped pipeline is a single phase anyway
+        const bool      multi_on = oe && !strcmp(oe, "all");
+        if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
             // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test
@@ -1370,13 +1430,14 @@ int dfft_plan_tune(dfft_plan_t plan) {
 int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     if (!plan || !buf || len < 64) return fail(DFFT_EINVAL, "dfft_plan_describe: bad arguments");
     const dfft_plan_s* p = plan;
-    const long long    cp = p->chunk_planes > 0 ? p->chunk_planes : p->xs;
+    const bool         one = p->zy_on && !(p->flags & DFFT_PLAN_UNFUSED);
+    const long long    cp = one ? zy_phase_planes(p, p->xs) : (p->chunk_planes > 0 ? p->chunk_planes : p->xs);
     const long long    nch = cp > 0 ? (p->xs + cp - 1) / cp : 1;
     const bool         fused = !(p->flags & DFFT_PLAN_UNFUSED);
     snprintf(buf, (size_t)len,
              "pipeline=%s yz_stage=%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d",
              (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
-             (p->zy_on && fused && !p->exch && p->wbuf) ? "one-launch" : "two-launches-per-chunk", nch, cp,
+             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", nch, cp,
              (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0);
     return DFFT_OK;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dfft_kernels.h"
+
 namespace dfft {
 
 enum { ZY_MAX_PLANES = 4096 };
@@ -23,13 +25,21 @@ struct ZyLaunch {
     void*       w;          // hand-over buffer: rows N2 apart, planes w_plane elements apart
     void*       dst;        // backward: [plane][N1][N2], planes dst_plane elements apart
     long long   src_plane, w_plane, dst_plane;
-    long long   nplanes, chunk;  // planes; planes per Infinity-Cache phase
+    long long   plane0, nplanes, chunk;  // first plane and number of planes of this launch; planes per Infinity-Cache phase
     ZyCtl*      ctl;
-    unsigned    generation;  // how many launches this control block has served (all with the same geometry and direction)
+    unsigned    ticket_base;  // value of ctl->ticket when this launch starts (the host adds zy_tickets() per launch)
+    unsigned    done_base;    // value of ctl->done[plane] of this launch's planes when it starts (producers per plane x executes so far)
+    int         packed;       // the column side that is not w is the packed exchange layout `pk` (forward: dst, backward: src)
+    AxisMap     pk;           // FFT index -> offset inside the packed layout (blocks of pk.blk rows per destination / sub-block)
+    long long   pk_plane;     // distance between consecutive X planes inside a block of the packed layout
+    RotMap      rot;          // rot != 0: rows of the packed layout are rotated by rot * (plane + a0) elements (mask = N2 - 1)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
 };
 
 bool       zy_supported(int dtype, int n1, int n2);
+long long  zy_grid();
+unsigned   zy_units_per_plane(int n1, int n2, int dir, unsigned* producers);
+unsigned   zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk);
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream);
 
 }  // namespace dfft

@@ -18,8 +18,9 @@
 // prefetched only if its dependency is already satisfied).  Every spin is bounded by the wall clock; a time-out sets ctl->error,
 // every workgroup leaves, and the host reports it at the next synchronisation (and goes back to the two-launch path).
 //
-// Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes), single-GPU
-// fused plans with the padded hand-over buffer.  Everything else keeps the chunk loop.
+// Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes); single-GPU fused
+// plans (hand-over buffer or bufferDev1 as w) and P > 1 fused plans with even splits (the Y side then reads / writes the packed,
+// row-rotated exchange layout), whole slabs or the X-plane parts of the overlapped pipeline.  Everything else keeps the chunk loop.
 #include "dfft_fft_impl.h"
 #include "dfft_zy.h"
 
@@ -32,11 +33,13 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 
 // DIR = +1: producers = Z rows (src -> w), consumers = Y columns (w in place)
 // DIR = -1: producers = Y columns (w in place), consumers = Z rows (w -> dst)
-template <class PZ, class PY, int DIR>
+// PACK: the column side that is not w is the packed exchange layout of a P > 1 plan (forward: Y columns w -> packed send buffer,
+// backward: packed receive buffer -> w) described by the launcher's axis map `pk`, with the rows rotated per plane (RotMap mode 1)
+template <class PZ, class PY, int DIR, bool PACK>
 __global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
-                long long src_plane, long long w_plane, long long dst_plane, unsigned nplanes, unsigned chunk, unsigned ticket_base,
-                unsigned done_base) {
+                long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
+                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm) {
     using V = double2;
     constexpr int CB = 8;  // column tiles of one cache line
     constexpr int THREADS = CB * PY::T;
@@ -78,10 +81,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         const unsigned c = t / (CH * BB), r = t - c * (CH * BB);
         if (r < CH * UA) {
             const unsigned pl = c * CH + r / UA;
-            if (pl < nplanes) it = Item{t, PROD, pl, r % UA};
+            if (pl < nplanes) it = Item{t, PROD, plane0 + pl, r % UA};
         } else {
             const unsigned r2 = r - CH * UA, pl = c * CH + r2 / UB;
-            if (pl < nplanes) it = Item{t, CONS, pl, r2 % UB};
+            if (pl < nplanes) it = Item{t, CONS, plane0 + pl, r2 % UB};
         }
         return it;
     };
@@ -127,6 +130,22 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     auto wrsrc = [&](unsigned plane) {  // buffer descriptor of one plane of w (offsets inside a plane fit 32 bits)
         return __builtin_amdgcn_make_buffer_rsrc((void*)(w + (long long)plane * w_plane), 0, (int)((size_t)N1 * N2 * sizeof(V)), 0x00020000);
     };
+    // packed side (PACK): point jy + TY k of a column lies in block (TY k) / pk.blk of the map -- the launcher guarantees
+    // pk.blk % TY == 0, so the block term is wave-uniform per k (computed once) -- plus one per-thread term and the tile's base
+    unsigned pk_uni[PACK ? E : 1];
+    if constexpr (PACK) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int ib = (TY * k) / pk.blk;
+            pk_uni[k] = (unsigned)(block_term(pk, ib) + (long long)(TY * k - ib * pk.blk) * pk.stride);
+        }
+    }
+    const long long pk_thr = PACK ? (long long)jy * pk.stride + cy : 0ll;
+    auto            pk_base = [&](unsigned plane, unsigned un) -> long long {  // tile base: the plane's rows, rotated tile position
+        int col = (int)(un * CB);
+        if (rm.rot != 0) col = (col + rm.rot * (int)(plane + (unsigned)rm.a0)) & rm.mask;
+        return (long long)plane * pk_plane + col + pk_thr;
+    };
     constexpr bool ROWS_PRODUCE = DIR > 0;  // which kind of unit hands its results over through w
     // ---- row units (Z): forward src -> w (sc1 stores), backward w (sc1 loads) -> dst
     auto load_rows = [&](unsigned plane, unsigned un, V* d) {
@@ -166,6 +185,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
                 const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
                 d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
             }
+        } else if constexpr (PACK) {
+            const V* ip = src + pk_base(plane, un);  // the receive buffer, written before this launch: streamed, plain visibility
+#pragma unroll
+            for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + pk_uni[k]);
         } else {
             const V* ip = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
 #pragma unroll
@@ -173,7 +196,11 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         }
     };
     auto store_cols = [&](unsigned plane, unsigned un, const V* v) {
-        if constexpr (ROWS_PRODUCE) {
+        if constexpr (ROWS_PRODUCE && PACK) {
+            V* op = dst + pk_base(plane, un);  // the send buffer: not read again by this device, streamed out
+#pragma unroll
+            for (int k = 0; k < E; ++k) gstore<true>(op + pk_uni[k], v[k]);
+        } else if constexpr (ROWS_PRODUCE) {
             V* op = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
 #pragma unroll
             for (int k = 0; k < E; ++k) op[(long long)(TY * k) * N2] = v[k];
@@ -237,41 +264,30 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     }
 }
 
-template <class PZ, class PY, int DIR> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
+template <class PZ, class PY, int DIR, bool PACK> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
     constexpr int    THREADS = 8 * PY::T, GR = THREADS / PZ::T;
     constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * 8 * sizeof(double2);
     constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
-    auto             kern = zy_chunk_kernel<PZ, PY, DIR>;
-    static std::atomic<int> blocks_per_cu[64];
-    static std::mutex       setup_mutex;
-    int                     dev = 0;
-    hipError_t              e = hipGetDevice(&dev);
+    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK>;
+    static std::atomic<bool> attr_set[64];
+    static std::mutex        setup_mutex;
+    int                      dev = 0;
+    hipError_t               e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lk(setup_mutex);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
         if (e != hipSuccess) return e;
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, THREADS, LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            occ = 1;
-        }
-        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
+        attr_set[dev].store(true, std::memory_order_release);
     }
+    if (PACK && (L.pk.blk <= 0 || L.pk.blk % PY::T != 0 || L.pk.last_delta != 0)) return hipErrorInvalidValue;
     // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing)
-    const long long grid = device_info().cus;
+    const long long grid = zy_grid();
     (void)hipGetLastError();
-    // every workgroup takes tickets until it sees one past the end: the counter advances by total + overshoot per launch, where the
-    // overshoot is exactly 2 per workgroup (two tickets are held ahead) -- the same count every time, so the next launch's base is known
-    constexpr unsigned UZ = PY::N / GR, UY = PZ::N / 8, BB = UZ + UY, UA = DIR > 0 ? UZ : UY;
-    const unsigned     nchunks = (unsigned)((L.nplanes + L.chunk - 1) / L.chunk);
-    const unsigned     total = nchunks * (unsigned)L.chunk * BB;
-    const unsigned     per_launch = total + 2u * (unsigned)grid;
-    const unsigned     ticket_base = (unsigned)L.generation * per_launch, done_base = (unsigned)L.generation * UA;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
-                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.nplanes, (unsigned)L.chunk,
-                       ticket_base, done_base);
+                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.plane0, (unsigned)L.nplanes,
+                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot);
     return hipGetLastError();
 }
 
@@ -282,11 +298,27 @@ using P512 = Plan<512, 8, 8, 8, 8>;
 
 bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512) && (n2 == 256 || n2 == 512); }
 
+// workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
+// advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.
+long long zy_grid() { return device_info().cus; }
+unsigned  zy_units_per_plane(int n1, int n2, int dir, unsigned* producers) {
+    const int      ty = n1 / 8, tz = n2 / 8, threads = 8 * ty, gr = threads / tz;
+    const unsigned uz = (unsigned)(n1 / gr), uy = (unsigned)(n2 / 8);
+    if (producers) *producers = dir > 0 ? uz : uy;
+    return uz + uy;
+}
+unsigned zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk) {
+    const unsigned nchunks = (unsigned)((nplanes + chunk - 1) / chunk);
+    return nchunks * (unsigned)chunk * zy_units_per_plane(n1, n2, dir, nullptr) + 2u * (unsigned)zy_grid();
+}
+
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
-    if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
-#define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                  \
-    if (L.n2 == NZ && L.n1 == NY)                                                      \
-        return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1>(L, stream) : launch_zy_t<PZ_, PY_, -1>(L, stream);
+    if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
+#define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
+    if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
+        if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \
+        return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false>(L, stream) : launch_zy_t<PZ_, PY_, -1, false>(L, stream);            \
+    }
     DFFT_ZY_CASE(512, 512, P512, P512)
     DFFT_ZY_CASE(256, 256, P256, P256)
     DFFT_ZY_CASE(512, 256, P512, P256)

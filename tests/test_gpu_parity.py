@@ -323,6 +323,36 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
     assert (outs["1"][1] / n - a).abs().max().item() < 1e-11
 
 
+@pytest.mark.parametrize("rot", ["0", "1"])
+@pytest.mark.parametrize("N,P", [((8, 256, 256), 2), ((16, 256, 512), 4), ((16, 512, 256), 2), ((32, 256, 256), 8), ((24, 512, 512), 4)])
+def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatch):
+    """P > 1: the one-launch YZ stage stores its column results straight into the packed (and, with DFFT_ROT=1, row-rotated) send
+    layout, the inverse reads the packed receive layout -- whole slabs in the serial pipeline, X-plane parts in the overlapped
+    one.  Bit-identical to two launches per chunk in both directions; against the oracle once."""
+    from distributedfft_amd import api
+    monkeypatch.setenv("DFFT_ROT", rot)
+    monkeypatch.setenv("DFFT_CHUNK_PLANES", "3")   # several phases per slab / part
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=77 + P)
+    ref = so.fftn_reference(x, P)
+    inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "all" if mode == "1" else "0")   # P > 1 plans use the stage only on request
+        for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP):
+            fwd, _ = _run_plans(gpu, N, P, "f64", x, +1, flags, inputs)
+            bwd, _ = _run_plans(gpu, N, P, "f64", None, -1, flags, [r for r in ref])
+            res[(mode, flags)] = (fwd, bwd)
+    scale = max(np.abs(r).max() for r in ref)
+    for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP):
+        for d in range(P):
+            cnt = ref[d].size
+            assert np.array_equal(res[("1", flags)][0][d][:cnt], res[("0", flags)][0][d][:cnt]), (N, P, flags, d)
+            assert np.abs(res[("1", flags)][0][d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < 1e-11
+            cnt = inputs[d].size
+            assert np.array_equal(res[("1", flags)][1][d][:cnt], res[("0", flags)][1][d][:cnt]), (N, P, flags, d, "backward")
+
+
 def test_plan_tune_keeps_results_bit_identical(gpu):
     """dfft_plan_tune (plan-time placement measurement of the hand-over buffer): a plan that owns such a buffer -- planes a
     multiple of 1 MiB apart, slab beyond the 256 MiB Infinity Cache -- probes its candidates with the X-pass kernel alone
