@@ -232,12 +232,12 @@ class Plan:
 
     def tune_report(self) -> dict:
         """{'candidates_ms': [...], 'kept': i, 'kept_retimed_ms': t} of the last tune() (dfft_plan_tune_report)."""
-        ms = (C.c_double * 16)()
+        ms = (C.c_double * 128)()
         kept, fin = C.c_int(-1), C.c_double(0.0)
-        n = L.load().dfft_plan_tune_report(self.handle, 16, ms, C.byref(kept), C.byref(fin))
+        n = L.load().dfft_plan_tune_report(self.handle, 128, ms, C.byref(kept), C.byref(fin))
         if n < 0:
             L.check(n, "dfft_plan_tune_report")
-        return {"candidates_ms": [round(ms[i], 4) for i in range(min(n, 16))], "kept": kept.value, "kept_retimed_ms": round(fin.value, 4)}
+        return {"candidates_ms": [round(ms[i], 4) for i in range(min(n, 128))], "kept": kept.value, "kept_retimed_ms": round(fin.value, 4)}
 
     def set_scale(self, s: float) -> None:
         """Multiply the result of every later execute by s (folded into the X-pass kernel; 1.0 = the reference's

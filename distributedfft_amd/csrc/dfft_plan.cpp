@@ -220,10 +220,10 @@ struct dfft_plan_s {
     bool                    long_axis = false;
     void*                   lbuf = nullptr;
     // Placement of the hand-over buffer (dfft_plan_tune).  The X pass runs 5-8 % faster when the buffer it reads and the
-    // buffer it writes lie in different regions of the device's physical memory (regions are 10+ GiB long, consecutive
+    // buffer it writes lie in different regions of the device's physical memory (regions are 4 ... 70 GiB long, consecutive
     // allocations usually share one; profiles/r03/README.md section 1, tools/xprobe.hip), so tuning times the X-pass kernel
-    // alone on a few candidate allocations -- spacer allocations in between move the candidates across region boundaries --
-    // and keeps the one on which it ran fastest.
+    // alone on candidate allocations made one after the other -- all kept alive, so that each moves the next one on -- until
+    // one behaves differently, and keeps the one on which it ran fastest.
     // t0 as one persistent launch (dfft_zy.hip) instead of two launches per cache chunk: single-GPU fused plans in fp64 whose Y and
     // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
     ZyCtl*                  zy_ctl = nullptr;
@@ -1308,24 +1308,21 @@ int dfft_plan_tune(dfft_plan_t plan) {
     dfft_plan_s* p = plan;
     DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
     const size_t wbytes = (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype);
-    // Candidates: the current buffer, then fresh allocations with a spacer in front of each.  The regions that matter are tens
-    // of GiB long (one 128 GiB allocation is half and half; tools/xprobe.hip, profiles/r03/experiments/xprobe_*.log) and the
-    // driver hands out device memory top-down, so a spacer that stays allocated moves the next candidate that far on.  The
-    // spacers grow -- 8, 8, 16, 32, 64, 32 GiB -- so that seven candidates reach 170 GiB, more than half of the device (some processes
-    // see no change of behaviour over 130 GiB: profiles/r03/experiments/tune_check_*.log); bounded by DFFT_TUNE_TRIES (default 7)
-    // and by what is free (the transient footprint never exceeds 70 % of the free device memory).  DFFT_TUNE_SPACER_MB fixes the
-    // spacer size instead.
-    int         max_tries = 7;
+    // Candidates: the current buffer, then fresh allocations of the same size, ALL kept until the end.  The driver hands out
+    // device memory block by block (runs of 2 ... 36 consecutive 2 GiB allocations behave alike, then the behaviour flips:
+    // tools/xprobe.hip census, profiles/r03/experiments/xprobe_census_*.log, placement_state.log), so every allocation that stays
+    // alive moves the next one on, and walking densely cannot step over a short run the way a few large strides can (an
+    // earlier version placed seven candidates behind spacers of 8 ... 64 GiB; on some boxes all of them behaved like the first
+    // one: experiments/tune_check_final.log).  The walk ends at the first candidate that is 3 % away from another one (the two
+    // behaviours are 5-8 % apart), after DFFT_TUNE_TRIES candidates (default 128), or when the transient footprint would exceed
+    // 70 % of the free device memory; one probe costs about 7 X passes.  DFFT_TUNE_SPACER_MB puts a spacer in front of every
+    // candidate (coarser, further-reaching walk).
+    int         max_tries = 128;
     const char* mt = getenv("DFFT_TUNE_TRIES");
     if (mt && atoi(mt) > 0) max_tries = atoi(mt);
-    long long   fixed_spacer = -1;
+    size_t      spacer_bytes = 0;
     const char* sm = getenv("DFFT_TUNE_SPACER_MB");
-    if (sm && atoll(sm) >= 0) fixed_spacer = atoll(sm) << 20;
-    auto spacer_for = [&](int k) -> size_t {  // spacer in front of candidate k (k >= 1)
-        if (fixed_spacer >= 0) return (size_t)fixed_spacer;
-        static const int gib[] = {8, 8, 16, 32, 64, 32};
-        return (size_t)gib[std::min(k - 1, 5)] << 30;
-    };
+    if (sm && atoll(sm) > 0) spacer_bytes = (size_t)atoll(sm) << 20;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
         (void)hipGetLastError();
@@ -1338,16 +1335,10 @@ int dfft_plan_tune(dfft_plan_t plan) {
     int   rc = probe_x_pass(p, p->wbuf, &ms);
     if (rc) return rc;
     p->w_ms.push_back(ms);
-    std::vector<int> cand_of_ms(1, 0);
-    size_t           used = 0;
-    while ((int)cand.size() < max_tries && used + spacer_for((int)cand.size()) + wbytes <= budget) {
-        const size_t spacer_bytes = spacer_for((int)cand.size());
-        float lo = p->w_ms[0], hi = p->w_ms[0];
-        for (float v : p->w_ms) {
-            lo = std::min(lo, v);
-            hi = std::max(hi, v);
-        }
-        if (cand.size() >= 2 && lo < 0.97f * hi) break;  // both placements seen (they are 5-8 % apart): keep the fast one
+    float  lo = ms, hi = ms;
+    size_t used = 0;
+    while ((int)cand.size() < max_tries && used + spacer_bytes + wbytes <= budget) {
+        if (lo < 0.97f * hi) break;  // both behaviours seen: keep the fast one
         void *sp = nullptr, *nw = nullptr;
         if (spacer_bytes > 0) {
             if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
@@ -1365,57 +1356,20 @@ int dfft_plan_tune(dfft_plan_t plan) {
         rc = probe_x_pass(p, nw, &ms);
         if (rc) break;
         p->w_ms.push_back(ms);
-        cand_of_ms.push_back((int)cand.size() - 1);
+        lo = std::min(lo, ms);
+        hi = std::max(hi, ms);
     }
-    auto spread_seen = [&]() {
-        float lo = p->w_ms[0], hi = p->w_ms[0];
-        for (float v : p->w_ms) {
-            lo = std::min(lo, v);
-            hi = std::max(hi, v);
-        }
-        return lo < 0.97f * hi;
-    };
     (void)hipStreamSynchronize(p->stream);
     for (void* sp : spacers) (void)hipFree(sp);
-    spacers.clear();
-    if (rc == DFFT_OK && !spread_seen() && cand.size() > 1 && !(mt && atoi(mt) > 0)) {
-        // Second phase: everything tried so far behaved alike.  The walk above only moves DOWN in address; memory above this
-        // process's first allocation may have become free meanwhile (a previous process's buffers are released lazily by the
-        // driver), and a fresh request is served from the highest free address.  Give the later candidates back, wait a
-        // moment, and try two more.
-        for (size_t i = 1; i < cand.size(); ++i) (void)slab_free(cand[i]);
-        cand.resize(1);
-        for (size_t i = 1; i < cand_of_ms.size(); ++i) cand_of_ms[i] = -1;
-        std::this_thread::sleep_for(std::chrono::milliseconds(60));
-        for (int extra = 0; extra < 2 && rc == DFFT_OK && !spread_seen(); ++extra) {
-            void *sp = nullptr, *nw = nullptr;
-            if (extra == 1 && used + ((size_t)24 << 30) <= budget && hipMalloc(&sp, (size_t)24 << 30) == hipSuccess) spacers.push_back(sp);
-            else (void)hipGetLastError();
-            if (slab_alloc(&nw, wbytes) != hipSuccess) {
-                (void)hipGetLastError();
-                break;
-            }
-            cand.push_back(nw);
-            rc = probe_x_pass(p, nw, &ms);
-            if (rc) break;
-            // the report keeps one entry per buffer tried; entries of buffers already given back stay where they are
-            p->w_ms.push_back(ms);
-            cand_of_ms.push_back((int)cand.size() - 1);
-        }
-        for (void* sp : spacers) (void)hipFree(sp);
-    }
-    // w_ms[i] belongs to candidate cand_of_ms[i] (-1: given back before the end)
-    int best_ms = -1;
-    for (int i = 0; i < (int)p->w_ms.size(); ++i) {
-        if (cand_of_ms[i] < 0) continue;
-        if (best_ms < 0 || p->w_ms[i] < 0.985f * p->w_ms[best_ms]) best_ms = i;  // a later candidate must be clearly faster
-    }
-    const int best = cand_of_ms[best_ms];
+    // w_ms[i] belongs to candidate i (a failed probe leaves one candidate without an entry)
+    int best = 0;
+    for (int i = 1; i < (int)p->w_ms.size(); ++i)
+        if (p->w_ms[i] < 0.985f * p->w_ms[best]) best = i;  // a later candidate must be clearly faster
     (void)hipStreamSynchronize(p->stream);
     for (int i = 0; i < (int)cand.size(); ++i)
         if (i != best) (void)slab_free(cand[i]);
     p->wbuf = cand[best];
-    p->w_kept = best_ms;
+    p->w_kept = best;
     if (rc) return rc;
     // the kept buffer once more, now that its neighbours are gone (reported, not acted upon)
     rc = probe_x_pass(p, p->wbuf, &p->w_final_ms);

@@ -164,9 +164,11 @@ int dfft_plan_sync(dfft_plan_t plan);
  * single-GPU plan reads the plan's internal hand-over buffer and writes the result buffer; it runs 5-8 % faster when the two
  * lie in different regions of the device's physical memory (profiles/r03/README.md section 1), which consecutive allocations
  * usually do not.  dfft_plan_tune times that ONE kernel -- seven launches of ~0.7 ms per candidate, no complete transforms --
- * on the current buffer and on up to DFFT_TUNE_TRIES - 1 (default 6) fresh allocations with growing spacer allocations (8 ... 64
- * GiB; the regions are tens of GiB long) in between, stops as soon as two candidates differ by 3 %, keeps the fastest and frees
- * everything else (transient footprint: at most 70 % of the free device memory).  The probe launches overwrite the result buffer (forward plans) with garbage:
+ * on the current buffer and on fresh allocations of the same size made one after the other and all kept until the end (memory
+ * is handed out in runs of 2 ... 36 such allocations that behave alike, so a dense walk cannot step over a run), stops as soon
+ * as two candidates differ by 3 %, keeps the fastest and frees everything else.  Bounds: DFFT_TUNE_TRIES candidates (default
+ * 128) and a transient footprint of at most 70 % of the free device memory; worst case about a second at 512^3 fp64.  The probe
+ * launches overwrite the result buffer (forward plans) with garbage:
  * call it before the first execute, not between an execute and the use of its result.  A no-op for plans without such a
  * buffer (P > 1, un-fused, natural-order, cache-resident sizes) and with DFFT_TUNE=0.  Results of later executes are
  * bit-identical with and without tuning.  The reference-named wrapper fft_mpi_plan_dft_c2c_3d, distFFTOpt, speed3d_c2c and

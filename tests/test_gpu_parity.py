@@ -374,7 +374,7 @@ def test_plan_tune_keeps_results_bit_identical(gpu):
     p1 = api.Plan(*N, a, b1, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
     p1.tune()
     rep = p1.tune_report()
-    assert 1 <= len(rep["candidates_ms"]) <= 9 and 0 <= rep["kept"] < len(rep["candidates_ms"]) and rep["kept_retimed_ms"] > 0
+    assert 1 <= len(rep["candidates_ms"]) <= 128 and 0 <= rep["kept"] < len(rep["candidates_ms"]) and rep["kept_retimed_ms"] > 0
     assert min(rep["candidates_ms"]) > 0
     p1.execute(api.EXEC_NO_TIMING)
     p1.sync()
