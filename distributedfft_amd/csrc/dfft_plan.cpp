@@ -1155,7 +1155,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         const long long ysub = p->sy.blk / std::max(1, p->ycuts);
         const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2);
-        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && ysub % (n1 / 8) == 0;  // even splits; a
+        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % (n1 / 8) == 0;  // even splits; a
                                    // destination block is a whole number of the column unit's 8-point-per-thread strides
         // P > 1 plans only on request (DFFT_T0_ONE_LAUNCH=all): measured per rank at 512^3 fp64 the packed form gains nothing over two
         // launches per chunk (P = 4: 0.339 vs 0.338 ms; profiles/r03/experiments/local_by_P_one_launch.log) -- the Y units then
@@ -1195,7 +1195,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
             long long       fit = std::max(1ll, (mb << 20) / plane_b);
             if (plane_b >= (8ll << 20) && fit > 1) --fit;
-            const long long nchunks = (p->xs + fit - 1) / fit;
+            const long long nchunks = std::max(1ll, (p->xs + fit - 1) / fit);
             p->chunk_planes = (p->xs + nchunks - 1) / nchunks;
         }
         const char* cpe = getenv("DFFT_CHUNK_PLANES");

@@ -27,9 +27,9 @@ DST = ROOT / "profiles" / ROUND
 
 def short(name: str) -> str:
     m = re.search(r"fft_tiles_kernel<(.*?), dfft::Plan<(\d+), (\d+)[^>]*>, (\d+), (\d+), (-?\d+), (true|false), dfft::(\w+)>", name)
-    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)>", name)
+    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)(?:, (true|false))?>", name)
     if mz:  # t0 as one persistent launch (dfft_zy.hip)
-        return f"zy_chunk_kernel f64 NZ={mz.group(1)} NY={mz.group(2)} dir={mz.group(3)} (one-launch YZ stage)"
+        return f"zy_chunk_kernel f64 NZ={mz.group(1)} NY={mz.group(2)} dir={mz.group(3)}{' packed' if mz.group(4) == 'true' else ''} (one-launch YZ stage)"
     if not m:
         m2 = re.search(r"fft_generic_kernel<(.*?), (-?\d+)>", name)
         if m2:
@@ -45,7 +45,7 @@ def stats(run: str, out: str):
     if not files:
         print("no kernel stats for", run)
         return
-    rows = list(csv.DictReader(open(max(files, key=lambda f: Path(f).stat().st_size))))
+    rows = list(csv.DictReader(open(max(files, key=lambda f: Path(f).stat().st_mtime))))
     rows.sort(key=lambda r: ("dfft::" not in r["Name"], -float(r["TotalDurationNs"])))
     with open(DST / out, "w", newline="") as f:
         w = csv.writer(f)
@@ -53,6 +53,33 @@ def stats(run: str, out: str):
         for r in rows:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"],
                         r["StdDev"]])
+    print("wrote", DST / out)
+
+
+def timed_region(run: str, out: str, steps: int = 20):
+    """The library's kernels over the LAST `steps` forward executes of the trace (bench.py's timed region).  The plain --stats
+    averages above also contain the warm-up executes and dfft_plan_tune's probe launches of the X-pass kernel (7 per candidate
+    buffer, most of them on slow placements), so the X pass reads slower there than it runs in the pipeline."""
+    files = glob.glob(str(SRC / run / "**" / "*kernel_trace.csv"), recursive=True)
+    if not files:
+        print("no kernel trace for", run)
+        return
+    rows = [r for r in csv.DictReader(open(max(files, key=lambda f: Path(f).stat().st_mtime))) if "dfft::" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    names = [short(r["Kernel_Name"]) for r in rows]
+    # bench.py ends with one backward execute (round-trip check): cut at the last forward X pass
+    last = max(i for i, n in enumerate(names) if "TuneTransposedStore" in n and "dir=1" in n)
+    xs = [i for i in range(last + 1) if "TuneTransposedStore" in names[i] and "dir=1" in names[i]]
+    first = xs[-steps - 1] + 1 if len(xs) > steps else 0  # the region starts behind the X pass of the execute before it
+    per = defaultdict(list)
+    for i in range(first, last + 1):
+        per[names[i]].append(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"]))
+    with open(DST / out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel (last %d forward executes of the trace = the timed region)" % steps, "Calls", "AverageNs", "MinNs", "MaxNs"])
+        for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if v:
+                w.writerow([k, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
     print("wrote", DST / out)
 
 
@@ -64,7 +91,7 @@ def pmc():
         if not files:
             continue
         acc = defaultdict(list)
-        for r in csv.DictReader(open(max(files, key=lambda f: Path(f).stat().st_size))):
+        for r in csv.DictReader(open(max(files, key=lambda f: Path(f).stat().st_mtime))):
             if "dfft::" not in r["Kernel_Name"] and "copyBuffer" not in r["Kernel_Name"]:
                 continue  # only the library's kernels (and the runtime's copy kernel as a calibration point)
             key = (short(r["Kernel_Name"]), r["Counter_Name"], r.get("Grid_Size", ""), r.get("VGPR_Count", ""),
@@ -126,5 +153,6 @@ def pmc():
 if __name__ == "__main__":
     DST.mkdir(parents=True, exist_ok=True)
     stats("trace_default", "bench_512_fp64_P1_kernel_stats.csv")
+    timed_region("trace_default", "bench_512_fp64_P1_timed_region.csv")
     stats("trace_nochunk", "bench_512_fp64_P1_nochunk_kernel_stats.csv")
     pmc()
