@@ -51,6 +51,9 @@ struct TuneDefault {
     static constexpr int CB_OVERRIDE = 0;  // columns per tile (0 = cols_per_tile())
     static constexpr bool PLAIN = false;   // single-block address maps: offsets = base + k*step (no per-point VGPRs)
     static constexpr bool PREFETCH = false; // issue the next tile's loads before processing the current one (+E complex VGPRs)
+    static constexpr bool FULL_PREFETCH = false;  // PREFETCH also where the second register set costs 64 VGPRs (16 points of 16 bytes)
+    static constexpr bool PLAIN_IN = false;  // single-block input map: offset = base + k * step (no per-point VGPRs on the load side)
+    static constexpr bool EARLY_WAIT = false;  // wait for the prefetched tile BEFORE this tile's stores are issued (pin_loaded)
     static constexpr bool ROT = false;      // row rotation of an exchange-buffer side compiled in (RotMap, dfft_kernels.h)
     static constexpr int ROT_IN = 0, ROT_OUT = 0;  // RotMap mode of the input / output side (compile time: 0, 1 or 2)
 };
@@ -77,8 +80,33 @@ struct TuneTransposedStore {
     static constexpr int CB_OVERRIDE = 0;
     static constexpr bool PLAIN = false;
     static constexpr bool PREFETCH = true;
+    static constexpr bool FULL_PREFETCH = false;
+    static constexpr bool PLAIN_IN = false;
+    static constexpr bool EARLY_WAIT = false;
     static constexpr bool ROT = false;
     static constexpr int ROT_IN = 0, ROT_OUT = 0;
+};
+// The same kernel for 16 points per thread (1024-point X pass) with a WHOLE second register set.  What made room: the input side
+// of the X pass is a single-block map (plane stride x FFT index), so the 16 per-point load offsets become one register plus
+// k * step with a wave-uniform step (PLAIN_IN), and the staged store's offsets were affine already -- 228 (half prefetch) ->
+// 25x VGPRs, no scratch (profiles/r03/kernel_resources.txt).  Why it matters: gfx9 counts loads and stores in ONE vmcnt, and with
+// both kinds outstanding the compiler has to wait for all of them, so a tile's exposed memory phases are what is NOT in flight
+// underneath its exchanges -- the half prefetch left two such phases per tile (the second half of the loads, then the stores)
+// and gained nothing in fp64 (profiles/r03/experiments/half_prefetch_ab.log); with the whole next tile in flight underneath the
+// exchanges only the store drain is left, the structure of the 512-point X pass.
+struct TuneTransposedStoreFull : TuneTransposedStore {
+    static constexpr bool FULL_PREFETCH = true;
+    static constexpr bool PLAIN_IN = true;
+};
+// EARLY_WAIT: the same vmcnt rule seen from the other side.  A prefetching kernel ends its iteration with "v = vnext", and that
+// copy has to wait for the prefetched loads -- with this tile's stores just issued the wait becomes vmcnt(0), i.e. the block
+// drains its own stores before it starts the next tile's arithmetic.  Waiting for the prefetched registers BEFORE the stores are
+// issued (they have had the whole tile's exchanges to arrive) lets the stores drain underneath the next tile instead.
+struct TuneTransposedStoreFullEarly : TuneTransposedStoreFull {
+    static constexpr bool EARLY_WAIT = true;
+};
+struct TuneTransposedStoreEarly : TuneTransposedStore {
+    static constexpr bool EARLY_WAIT = true;
 };
 
 // Column kernel default: the next tile's loads are issued before the current tile's exchanges (0.945 -> 0.869 ms on the
@@ -383,6 +411,13 @@ template <bool NT, class V> __device__ __forceinline__ void gstore(V* p, V v) {
     }
 }
 
+// "these registers are needed now": an empty asm that reads the value and clobbers memory -- the compiler has to complete the
+// loads that fill it before this point, and may not move later stores above it.  (Input only: an in/out operand would also pin
+// the value to an architectural VGPR from here on, and kernels at the 256-register limit keep part of the prefetched set in AGPRs.)
+__device__ __forceinline__ void pin_loaded(const double2& x) { asm volatile("" : : "v"(x.x), "v"(x.y) : "memory"); }
+__device__ __forceinline__ void pin_loaded(const float2& x) { asm volatile("" : : "v"(x.x), "v"(x.y) : "memory"); }
+__device__ __forceinline__ void pin_loaded(const cpair& x) { asm volatile("" : : "v"(x.x), "v"(x.y) : "memory"); }
+
 // register prefetch only where the second register set is cheap (64 VGPRs, i.e. E = 16 fp64: 1024-point columns
 // 4.6 -> 3.7 TB/s, round 1)
 #ifndef DFFT_PREFETCH_MAX_REGS
@@ -449,25 +484,26 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     // Per-thread element offsets of its E points relative to the tile base (constant over tiles).
     // PLAIN maps (one block, no uneven slab): offset = base + k * step with a wave-uniform step, no per-point VGPRs.
     constexpr bool PLAIN = Tune::PLAIN && !GENERAL && !KG::OSTAGE && !Tune::ROT;
+    constexpr bool PLAIN_IN = PLAIN || (Tune::PLAIN_IN && !GENERAL);
     constexpr int NREL = PLAIN ? 1 : E;
     constexpr int ON = N / LANES;  // staged store: memory elements (GV) per scalar column
     // staged store with ON a multiple of the group size (every power-of-two plan): the element a thread stores at step k is
     // tid + const_k in scalar column const'_k, so its offset is tid + C1_k + C2_k * cstride -- no per-point register
     // (and likewise when the group size is a multiple of ON: column tid / ON + const_k, element tid % ON)
     constexpr bool OAFFINE = KG::OSTAGE && (ON % GT == 0 || GT % ON == 0);
-    unsigned irel[NREL], orel[OAFFINE ? 1 : NREL];
+    unsigned irel[PLAIN_IN ? 1 : E], orel[OAFFINE ? 1 : NREL];
     unsigned ilast = 0, olast = 0;
     const unsigned istep = (unsigned)(T * imap.stride), ostep = (unsigned)(T * omap.stride);
-    if constexpr (PLAIN) {
-        irel[0] = (unsigned)(j * imap.stride + c * imap.cstride);
-        orel[0] = (unsigned)(j * omap.stride + c * omap.cstride);
-    }
+    if constexpr (PLAIN_IN) irel[0] = (unsigned)(j * imap.stride + c * imap.cstride);
+    if constexpr (PLAIN) orel[0] = (unsigned)(j * omap.stride + c * omap.cstride);
 #pragma unroll
     for (int k = 0; k < (PLAIN ? 0 : E); ++k) {
         const int idx = j + T * k;
-        const int ib = idx / imap.blk;
-        irel[k] = (unsigned)(block_term(imap, ib) + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
-        if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
+        if constexpr (!PLAIN_IN) {
+            const int ib = idx / imap.blk;
+            irel[k] = (unsigned)(block_term(imap, ib) + (idx - ib * imap.blk) * imap.stride + c * imap.cstride);
+            if (GENERAL && ib == imap.nblk - 1) ilast |= 1u << k;
+        }
         // staged store: thread owns the linear memory elements tid + GT*k of the [CB*LANES scalar columns][ON] result
         // tile (omap.cstride is then the distance between SCALAR columns, omap.stride the one between memory elements)
         // (two-phase tiles: points [0, E/2) belong to the image of columns [0, CB/2), the rest to the second image)
@@ -528,12 +564,19 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         int cb0 = (int)(b * CB);
         if constexpr (Tune::ROT_IN == 1) cb0 = (cb0 + rm.rot * (int)(a + (unsigned)rm.a0)) & rm.mask;
         const GV* ip = in + (long long)a * itile.a_stride + (long long)cb0 * itile.b_stride;
+        // (whole-tile prefetch: the per-point offsets irel[0] + k * istep and rotations rot_j + k * rot_t do not depend on the tile,
+        // and hoisted out of the tile loop -- which the compiler does -- they cost the very registers PLAIN_IN is there to free: the
+        // empty asm statements make them this iteration's values, computed next to the loads that use them)
+        int      rj = rot_j;
+        unsigned ir0 = irel[0];
+        if constexpr (Tune::ROT_IN == 2 && Tune::PLAIN_IN) asm volatile("" : "+v"(rj));
+        if constexpr (Tune::PLAIN_IN) asm volatile("" : "+v"(ir0));
         if (ok) {
 #pragma unroll
             for (int k = K0; k < K1; ++k) {
-                long long off = PLAIN ? (long long)(irel[0] + (unsigned)k * istep) : (long long)irel[PLAIN ? 0 : k];
+                long long off = PLAIN_IN ? (long long)(ir0 + (unsigned)k * istep) : (long long)irel[PLAIN_IN ? 0 : k];
                 if (GENERAL) off += ((ilast >> k) & 1u) ? (long long)a * imap.last_delta : 0ll;
-                if constexpr (Tune::ROT_IN == 2) off += (long long)(((cb0 + rot_j + k * rot_t) & rm.mask) - cb0);
+                if constexpr (Tune::ROT_IN == 2) off += (long long)(((cb0 + rj + k * rot_t) & rm.mask) - cb0);
                 dst[k - K0] = VT::from_g(gload<Tune::NTL>(ip + off));
             }
         } else {
@@ -543,7 +586,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     };
     auto load_tile = [&](unsigned t, V* dst) { load_part(t, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}); };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
-    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS) && KG::THREADS <= 512;
+    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH) && KG::THREADS <= 512;
     // 16 points per thread (1024- and 2048-point columns): a whole second register set does not fit (64 VGPRs: 4.6 -> 3.7 TB/s,
     // round 1), but the kernels leave room for HALF of one -- the first 8 points of the next tile are fetched underneath the
     // current tile's exchanges and stores, the other 8 at the top of the next iteration.  DFFT_HALF_PREFETCH=0 compiles it out.
@@ -605,6 +648,10 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 #pragma unroll
                     for (int l = 0; l < LANES; ++l) img[(c * LANES + l) * ROW + j + T * k] = VT::lane(cscale(v[k], sc), l);
                 group_sync<KG::WAVE_LOCAL>();
+                if constexpr (Tune::EARLY_WAIT && PF > 0) {
+#pragma unroll
+                    for (int k = 0; k < PF; ++k) pin_loaded(vnext[k]);
+                }
                 if (valid) {
 #pragma unroll
                     for (int k = 0; k < E; ++k) {
@@ -638,6 +685,10 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
                 }
             }
         } else if (valid) {
+            if constexpr (Tune::EARLY_WAIT && PF > 0) {
+#pragma unroll
+                for (int k = 0; k < PF; ++k) pin_loaded(vnext[k]);
+            }
 #pragma unroll
             for (int k = 0; k < E; ++k) {
                 long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
@@ -1088,8 +1139,21 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
     if constexpr (CBC * P::T <= 1024) {
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
+        using TTF = TuneTransposedStoreFull;
         constexpr bool can_stage = can_stage_store<V, P>();
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
+        // 16 points of 16 bytes per thread on full-line tiles (the 1024-point forward X pass, fp64 and fp32 pairs): whole-tile prefetch
+        // when the input side is a single-block map (TuneTransposedStoreFull); FFT_HINT_HALF_PREFETCH / FFT_HINT_EARLY_WAIT (the plan's
+        // DFFT_X_VARIANT=half|full|fullearly|early) select the other variants for A/B measurements.
+        constexpr bool can_full = can_stage && P::E == 16 && sizeof(V) == 16 && CBC * (int)sizeof(V) == 128 && CBC * P::T * GC <= 512;
+        using TTFE = TuneTransposedStoreFullEarly;
+        using TTE = TuneTransposedStoreEarly;
+        const bool single_in = L.imap.nblk == 1 && L.imap.sub <= 1 && L.imap.last_delta == 0;
+        const bool want_early = (L.hints & FFT_HINT_EARLY_WAIT) != 0;
+        const int  full = (can_full && staged && L.dir > 0 && single_in && !(L.hints & FFT_HINT_HALF_PREFETCH)) ? (want_early ? 2 : 1) : 0;
+        // (8 points per thread, the 512-point X pass: the early wait is a measurement switch only)
+        constexpr bool can_early = can_stage && P::N == 512 && sizeof(V) == 16;
+        const bool early = can_early && staged && L.dir > 0 && want_early;
         // half-line tiles (2048 points) with the transposing store: pair the two tiles of every 128-byte line in one workgroup
         // when columns are adjacent in memory on the input side (forward X pass)
         constexpr bool can_dual = P::S > 1 && sizeof(V) == 16 && 2 * CBC * sizeof(V) == 128 && (P::N & (P::N - 1)) == 0 && (P::N / VecTraits<V>::LANES) % (CBC * P::T) == 0 &&
@@ -1158,6 +1222,10 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneCols, 0, 1>>(L, stream);
             }
             if (L.dir > 0 && im == 2 && om == 0) {
+                if constexpr (can_full) {
+                    if (full == 2) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TTFE, 2, 0>>(L, stream);
+                    if (full == 1) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TTF, 2, 0>>(L, stream);
+                }
                 if constexpr (can_stage)
                     if (staged) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TT, 2, 0>>(L, stream);
                 return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneCols, 2, 0>>(L, stream);
@@ -1174,6 +1242,12 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
         }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
+            if constexpr (can_full) {
+                if (full == 2) return launch_variant<V, P, CBC, GC, +1, false, TTFE>(L, stream);
+                if (full == 1) return launch_variant<V, P, CBC, GC, +1, false, TTF>(L, stream);
+            }
+            if constexpr (can_early)
+                if (early) return launch_variant<V, P, CBC, GC, +1, false, TTE>(L, stream);
             if constexpr (can_stage)
                 if (staged) return launch_variant<V, P, CBC, GC, +1, false, TT>(L, stream);
             if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, TuneColsStreamOut>(L, stream);

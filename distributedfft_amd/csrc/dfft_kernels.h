@@ -72,6 +72,9 @@ struct FftLaunch {
 enum {
     FFT_HINT_STREAM_IN = 1,   // input is read once and must not displace the cache-resident chunk: non-temporal loads
     FFT_HINT_STREAM_OUT = 2,  // output goes to a different buffer and is not re-read soon: non-temporal stores
+    // kernel-variant switches of the staged transposing store (forward X pass); measurement switches, never change results
+    FFT_HINT_HALF_PREFETCH = 4,  // 16 points per thread: half-tile prefetch instead of the whole-tile one
+    FFT_HINT_EARLY_WAIT = 8,     // wait for the prefetched tile before this tile's stores are issued
 };
 
 bool fft_length_supported(int n);

@@ -230,6 +230,8 @@ struct dfft_plan_s {
     bool                    zy_on = false;
     unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
+    bool                    zy_lazy = false;           // DFFT_ZY_LAZY=1 when the plan was created: lazy-publish variant of the kernel
+    int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.
     int                     rot_elems = 0;
@@ -400,6 +402,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
     }
     static const int xgrid = env_grid("DFFT_X_GRID");
     L.grid_limit = xgrid;
+    L.hints |= p->x_hints;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
 
@@ -480,6 +483,7 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.ctl = p->zy_ctl;
     L.twz = twz;
     L.twy = twy;
+    L.lazy = p->zy_lazy ? 1 : 0;
     if (packed) {
         TileMap tile;
         packed_map(p, &L.pk, &tile);
@@ -1151,6 +1155,17 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         if (possible && !(re && *re == '0') && (pays || (re && *re == '1'))) p->rot_elems = (int)(3 * 128 / S);
     }
     {
+        // kernel-variant switches (A/B measurements; results are bit-identical either way), read when the plan is created:
+        //   DFFT_X_VARIANT=half|full|fullearly  1024-point forward X pass: half-tile prefetch / whole-tile prefetch (default) / + early wait
+        //   DFFT_X_VARIANT=early                512-point forward X pass: early wait for the prefetched tile
+        //   DFFT_ZY_LAZY=1                      one-launch YZ stage (P = 1): lazy publish, one quiet point per unit
+        const char* xv = getenv("DFFT_X_VARIANT");
+        if (xv && !strcmp(xv, "half")) p->x_hints = FFT_HINT_HALF_PREFETCH;
+        else if (xv && (!strcmp(xv, "fullearly") || !strcmp(xv, "early"))) p->x_hints = FFT_HINT_EARLY_WAIT;
+        const char* zl = getenv("DFFT_ZY_LAZY");
+        p->zy_lazy = zl && *zl && *zl != '0';
+    }
+    {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         const long long ysub = p->sy.blk / std::max(1, p->ycuts);
@@ -1389,10 +1404,11 @@ int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     const long long    nch = cp > 0 ? (p->xs + cp - 1) / cp : 1;
     const bool         fused = !(p->flags & DFFT_PLAN_UNFUSED);
     snprintf(buf, (size_t)len,
-             "pipeline=%s yz_stage=%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d",
+             "pipeline=%s yz_stage=%s%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d x_variant=%s",
              (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
-             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", nch, cp,
-             (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0);
+             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_lazy && !p->exch) ? "-lazy" : "", nch, cp,
+             (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0,
+             (p->x_hints & FFT_HINT_HALF_PREFETCH) ? "half-prefetch" : ((p->x_hints & FFT_HINT_EARLY_WAIT) ? "early-wait" : "default"));
     return DFFT_OK;
 }
 

@@ -35,7 +35,12 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 // DIR = -1: producers = Y columns (w in place), consumers = Z rows (w -> dst)
 // PACK: the column side that is not w is the packed exchange layout of a P > 1 plan (forward: Y columns w -> packed send buffer,
 // backward: packed receive buffer -> w) described by the launcher's axis map `pk`, with the rows rotated per plane (RotMap mode 1)
-template <class PZ, class PY, int DIR, bool PACK>
+// LAZY (measurement variant, DFFT_ZY_LAZY=1): gfx9 counts loads and stores in one vmcnt, so "wait for the prefetched unit" after a
+// unit's stores have been issued means "drain those stores" -- and a producer unit drains them again before it publishes.  The lazy
+// form waits for everything that is in flight (the previous unit's stores, the next unit's loads) after a unit's ARITHMETIC, when
+// it has had a whole unit's exchanges to complete, publishes the PREVIOUS producer unit there, and only then issues this unit's
+// stores, which drain underneath the next unit.  A workgroup never enters a blocking wait with an unpublished unit (flush first).
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
@@ -91,7 +96,8 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     auto share = [&](unsigned value_of_thread0) -> unsigned {
         if (tid == 0) shw[0] = value_of_thread0;
         __syncthreads();
-        const unsigned t = shw[0];
+        unsigned t = shw[0];
+        if constexpr (LAZY) t = __builtin_amdgcn_readfirstlane(t);  // block-uniform: keep the decoded item in scalar registers
         __syncthreads();
         return t;
     };
@@ -123,7 +129,9 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
             shw[1] = ok;
         }
         __syncthreads();
-        const bool ok = shw[1] != 0u;
+        unsigned okw = shw[1];
+        if constexpr (LAZY) okw = __builtin_amdgcn_readfirstlane(okw);
+        const bool ok = okw != 0u;
         __syncthreads();
         return ok;
     };
@@ -218,20 +226,25 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if (is_rows(it.kind)) load_rows(it.plane, it.unit, d);
         else load_cols(it.plane, it.unit, d);
     };
-    auto process_unit = [&](const Item& it, V* v) {
+    auto publish = [&](unsigned plane) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the unit's results have left this CU
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(&ctl->done[plane], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+    };
+    auto compute_unit = [&](const Item& it, V* v) {
         if (is_rows(it.kind)) {
             run_stages<V, PZ, 0, DIR, 1, true, true, TW_REG, TWPOW>(v, twzr, lds_row, jz, 0);
-            store_rows(it.plane, it.unit, v);
         } else {
             __syncthreads();  // the LDS rows of an earlier row unit are no longer read
             run_stages<V, PY, 0, DIR, CB, false, false, TW_REG, TWPOW>(v, twyr, lds, jy, cy);
+        }
+    };
+    auto store_unit = [&](const Item& it, const V* v) {
+        if (is_rows(it.kind)) {
+            store_rows(it.plane, it.unit, v);
+        } else {
             store_cols(it.plane, it.unit, v);
             __syncthreads();  // the tile is no longer read when the next unit scatters
-        }
-        if (it.kind == PROD) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the unit's results have left this CU
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&ctl->done[it.plane], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
         }
     };
 
@@ -243,32 +256,92 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if (!ready(cur, true)) return;
         load_unit(cur, v);
     }
-    while (cur.ticket < total) {
-        const unsigned t2 = take();
-        bool           loaded = false;
-        if (nxt.kind != NONE && ready(nxt, false)) {  // prefetch only what may be read already
-            load_unit(nxt, vn);
-            loaded = true;
-        }
-        if (cur.kind != NONE) process_unit(cur, v);
-        const Item nn = decode(share(t2));
-        if (nxt.kind != NONE && !loaded) {
-            if (!ready(nxt, true)) return;
-            load_unit(nxt, v);
-        } else if (loaded) {
+    if constexpr (!LAZY) {
+        while (cur.ticket < total) {
+            const unsigned t2 = take();
+            bool           loaded = false;
+            if (nxt.kind != NONE && ready(nxt, false)) {  // prefetch only what may be read already
+                load_unit(nxt, vn);
+                loaded = true;
+            }
+            if (cur.kind != NONE) {
+                compute_unit(cur, v);
+                store_unit(cur, v);
+                if (cur.kind == PROD) publish(cur.plane);
+            }
+            const Item nn = decode(share(t2));
+            if (nxt.kind != NONE && !loaded) {
+                if (!ready(nxt, true)) return;
+                load_unit(nxt, v);
+            } else if (loaded) {
 #pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = vn[k];
+                for (int k = 0; k < E; ++k) v[k] = vn[k];
+            }
+            cur = nxt;
+            nxt = nn;
         }
-        cur = nxt;
-        nxt = nn;
+    } else {
+        // One quiet point per unit, between its arithmetic and its stores: there everything the workgroup has in flight -- the
+        // previous unit's stores, the next unit's loads, the ticket atomic -- has had the unit's exchanges to complete, so the
+        // (all-or-nothing) vmcnt wait is short; the previous producer unit is published, the ticket read, the dependency of the
+        // unit after next polled.  After the stores nothing waits, so they drain underneath the next unit.
+        constexpr unsigned NOPLANE = 0xffffffffu;
+        unsigned           pend = NOPLANE;  // plane of a producer unit whose results are stored but not yet published
+        auto               flush = [&]() {
+            if (pend != NOPLANE) publish(pend);
+            pend = NOPLANE;
+        };
+        bool nxt_ok = false;  // the dependency of nxt is known to be satisfied (polled at an earlier quiet point)
+        while (cur.ticket < total) {
+            // the products of the stored twiddle powers (w^3 = w^1 w^2, ...) are loop-invariant, and hoisted out of the unit loop they
+            // would occupy the registers the power form exists to save (this variant then spills them): keep them per unit
+#pragma unroll
+            for (int i = 0; i < TWNZ; ++i) asm volatile("" : "+v"(twzr[i].x), "+v"(twzr[i].y));
+#pragma unroll
+            for (int i = 0; i < TWNY; ++i) asm volatile("" : "+v"(twyr[i].x), "+v"(twyr[i].y));
+            const unsigned t2 = take();
+            bool           loaded = false;
+            if (nxt.kind != NONE && (nxt_ok || ready(nxt, false))) {
+                load_unit(nxt, vn);
+                loaded = true;
+            }
+            Item nn{0u, NONE, 0u, 0u};
+            bool nn_ok = false;
+            if (cur.kind != NONE) {
+                compute_unit(cur, v);
+                flush();
+                if (loaded) {
+#pragma unroll
+                    for (int k = 0; k < E; ++k) pin_loaded(vn[k]);
+                }
+                nn = decode(share(t2));
+                nn_ok = nn.kind != CONS || ready(nn, false);
+                store_unit(cur, v);
+                if (cur.kind == PROD) pend = cur.plane;
+            } else {
+                nn = decode(share(t2));
+            }
+            if (nxt.kind != NONE && !loaded) {
+                flush();  // never wait for other workgroups while holding an unpublished unit
+                if (!ready(nxt, true)) return;
+                load_unit(nxt, v);
+            } else if (loaded) {
+#pragma unroll
+                for (int k = 0; k < E; ++k) v[k] = vn[k];
+            }
+            cur = nxt;
+            nxt = nn;
+            nxt_ok = nn_ok;
+        }
+        flush();
     }
 }
 
-template <class PZ, class PY, int DIR, bool PACK> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
     constexpr int    THREADS = 8 * PY::T, GR = THREADS / PZ::T;
     constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * 8 * sizeof(double2);
     constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
-    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK>;
+    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int                      dev = 0;
@@ -316,6 +389,7 @@ hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
 #define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
+        if (L.lazy && !L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
         if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \
         return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false>(L, stream) : launch_zy_t<PZ_, PY_, -1, false>(L, stream);            \
     }

@@ -300,11 +300,13 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
     x = so.random_input(N, seed=N[0] + 3)
     a = torch.from_numpy(x.reshape(-1)).to(gpu)
     outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", mode)
+    for mode in ("0", "1", "lazy"):  # "lazy": the lazy-publish variant of the kernel (DFFT_ZY_LAZY=1, a measurement switch)
+        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "0" if mode == "0" else "1")
+        monkeypatch.setenv("DFFT_ZY_LAZY", "1" if mode == "lazy" else "0")
         b, c = torch.zeros_like(a), torch.zeros_like(a)
         p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
         q = api.Plan(*N, b, c, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+        assert ("yz_stage=one-launch-lazy" in p.describe()) == (mode == "lazy"), p.describe()
         for _ in range(3):
             p.execute(api.EXEC_NO_TIMING)
         p.execute()
@@ -317,6 +319,7 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
         p.destroy()
         q.destroy()
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    assert torch.equal(outs["0"][0], outs["lazy"][0]) and torch.equal(outs["0"][1], outs["lazy"][1])
     ref = so.fftn_reference(x, 1)[0]
     got = outs["1"][0].cpu().numpy().reshape(ref.shape)
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
@@ -351,6 +354,36 @@ def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatc
             assert np.abs(res[("1", flags)][0][d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < 1e-11
             cnt = inputs[d].size
             assert np.array_equal(res[("1", flags)][1][d][:cnt], res[("0", flags)][1][d][:cnt]), (N, P, flags, d, "backward")
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("N,P,variants", [((1024, 32, 256), 1, ("half", "fullearly")), ((1024, 128, 256), 4, ("half", "fullearly")),
+                                          ((512, 24, 256), 1, ("early",)), ((512, 64, 256), 2, ("early",))])
+def test_x_pass_prefetch_variants_are_bit_identical(gpu, N, P, variants, prec, monkeypatch):
+    """Forward X pass through the staged transposing store with enough tiles for several grid-stride iterations per workgroup
+    (the prefetch carries data from one iteration to the next): the 1024-point kernel with the whole next tile prefetched (the
+    default), with half of it, and with the early wait; the 512-point kernel with the early wait (DFFT_X_VARIANT, measurement
+    switches) -- from the padded hand-over buffer (P = 1) and from the row-rotated receive buffer (P > 1).  Bit-identical to
+    each other, and within the tolerance of the oracle's numpy.fft.fftn."""
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    monkeypatch.setenv("DFFT_ROT", "1")
+    monkeypatch.setenv("DFFT_PAD", "1")
+    x = so.random_input(N, seed=n0 + 31 * P)
+    ref = so.fftn_reference(x, P)
+    inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    scale = max(np.abs(r).max() for r in ref)
+    monkeypatch.delenv("DFFT_X_VARIANT", raising=False)
+    base, _ = _run_plans(gpu, N, P, prec, x, +1, api.PLAN_INPUT_FROM_IN, inputs)
+    for d in range(P):
+        cnt = ref[d].size
+        assert np.abs(base[d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < TOL[prec], (N, P, d)
+    for var in variants:
+        monkeypatch.setenv("DFFT_X_VARIANT", var)
+        got, _ = _run_plans(gpu, N, P, prec, x, +1, api.PLAN_INPUT_FROM_IN, inputs)
+        for d in range(P):
+            cnt = ref[d].size
+            assert np.array_equal(got[d][:cnt], base[d][:cnt]), (N, P, var, d)
 
 
 def test_plan_tune_keeps_results_bit_identical(gpu):
