@@ -1158,12 +1158,12 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         // kernel-variant switches (A/B measurements; results are bit-identical either way), read when the plan is created:
         //   DFFT_X_VARIANT=half|full|fullearly  1024-point forward X pass: half-tile prefetch / whole-tile prefetch (default) / + early wait
         //   DFFT_X_VARIANT=early                512-point forward X pass: early wait for the prefetched tile
-        //   DFFT_ZY_LAZY=1                      one-launch YZ stage (P = 1): lazy publish, one quiet point per unit
+        //   DFFT_ZY_LAZY=0                      one-launch YZ stage (P = 1): the eager-publish kernel instead of the lazy one
         const char* xv = getenv("DFFT_X_VARIANT");
         if (xv && !strcmp(xv, "half")) p->x_hints = FFT_HINT_HALF_PREFETCH;
         else if (xv && (!strcmp(xv, "fullearly") || !strcmp(xv, "early"))) p->x_hints = FFT_HINT_EARLY_WAIT;
         const char* zl = getenv("DFFT_ZY_LAZY");
-        p->zy_lazy = zl && *zl && *zl != '0';
+        p->zy_lazy = !(zl && *zl == '0');  // default on: t0 of 512^3 fp64 1.278 -> 1.163 ms (profiles/r03/experiments/variant_ab.log)
     }
     {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
@@ -1176,7 +1176,13 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         // launches per chunk (P = 4: 0.339 vs 0.338 ms; profiles/r03/experiments/local_by_P_one_launch.log) -- the Y units then
         // stream their results to HBM instead of working in the cache, and a part of the overlapped pipeline is a single phase anyway
         const bool      multi_on = oe && !strcmp(oe, "all");
-        if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
+        // By itself only for 512 x 512-point planes (64 KiB units): with a 256-point axis in the plane the units are 32 KiB, a
+        // workgroup's per-unit overhead (ticket, dependency poll, quiet point) weighs twice as much and two launches per chunk win
+        // -- 256^3 fp64: t0 0.170 vs 0.216 ms (BASELINE config 2: 0.244 vs 0.298 ms per transform), 512 x 256 x 256: 0.357 vs
+        // 0.422, 256 x 256 x 512: 0.348 vs 0.424, against 256 x 512 x 512: 0.694 vs 0.593 (profiles/r03/experiments/
+        // variant_ab_256.log; two or three of the 256-thread workgroups per CU do not change that).  DFFT_T0_ONE_LAUNCH=1 / all force it.
+        const bool      pays = (n1 == 512 && n2 == 512) || (oe && *oe && *oe != '0');
+        if (!(oe && *oe == '0') && pays && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
             // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test

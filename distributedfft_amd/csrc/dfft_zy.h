@@ -34,7 +34,7 @@ struct ZyLaunch {
     long long   pk_plane;     // distance between consecutive X planes inside a block of the packed layout
     RotMap      rot;          // rot != 0: rows of the packed layout are rotated by rot * (plane + a0) elements (mask = N2 - 1)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
-    int         lazy;         // un-packed launches: the lazy-publish variant of the kernel (DFFT_ZY_LAZY=1, measurement switch)
+    int         lazy;         // un-packed launches: the lazy-publish variant of the kernel (the default; DFFT_ZY_LAZY=0: eager)
 };
 
 bool       zy_supported(int dtype, int n1, int n2);

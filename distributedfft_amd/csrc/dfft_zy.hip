@@ -355,7 +355,8 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (PACK && (L.pk.blk <= 0 || L.pk.blk % PY::T != 0 || L.pk.last_delta != 0)) return hipErrorInvalidValue;
-    // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing)
+    // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing -- nor do two or three of the
+    // 256-thread workgroups of 256-point Y axes, profiles/r03/experiments/variant_ab_256.log)
     const long long grid = zy_grid();
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,

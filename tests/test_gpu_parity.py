@@ -289,8 +289,9 @@ def test_untimed_executes_back_to_back_are_bit_identical(gpu):
 @pytest.mark.parametrize("N,chunk", [((16, 256, 256), 5), ((12, 512, 256), 4), ((9, 256, 512), 2), ((70, 512, 512), 64), ((512, 256, 256), 0)])
 def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
     """t0 as ONE persistent launch (dfft_zy.hip: ticket-ordered row and column units, sc1 hand-off through the hand-over buffer)
-    against the two launches per cache chunk it replaces: bit-identical results in both directions, with several chunks and a
-    ragged last chunk, also when executes are queued back to back; and against the oracle."""
+    against the two launches per cache chunk it replaces: with several chunks and a ragged last chunk, in both directions, also
+    when executes are queued back to back -- the eager-publish kernel bit-identical, the lazy-publish one (the default) equal
+    to the last bit or two and deterministic; and both against the oracle."""
     import torch
     from distributedfft_amd import api
     monkeypatch.setenv("DFFT_PAD", "1")            # small slabs get the hand-over buffer too
@@ -300,13 +301,13 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
     x = so.random_input(N, seed=N[0] + 3)
     a = torch.from_numpy(x.reshape(-1)).to(gpu)
     outs = {}
-    for mode in ("0", "1", "lazy"):  # "lazy": the lazy-publish variant of the kernel (DFFT_ZY_LAZY=1, a measurement switch)
+    for mode in ("0", "1", "lazy", "lazy2"):  # "1": the eager-publish kernel (DFFT_ZY_LAZY=0); "lazy": the default one, twice
         monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "0" if mode == "0" else "1")
-        monkeypatch.setenv("DFFT_ZY_LAZY", "1" if mode == "lazy" else "0")
+        monkeypatch.setenv("DFFT_ZY_LAZY", "1" if mode.startswith("lazy") else "0")
         b, c = torch.zeros_like(a), torch.zeros_like(a)
         p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
         q = api.Plan(*N, b, c, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
-        assert ("yz_stage=one-launch-lazy" in p.describe()) == (mode == "lazy"), p.describe()
+        assert ("yz_stage=one-launch-lazy" in p.describe()) == mode.startswith("lazy"), p.describe()
         for _ in range(3):
             p.execute(api.EXEC_NO_TIMING)
         p.execute()
@@ -319,11 +320,18 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
         p.destroy()
         q.destroy()
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
-    assert torch.equal(outs["0"][0], outs["lazy"][0]) and torch.equal(outs["0"][1], outs["lazy"][1])
+    # The lazy-publish kernel keeps the products of its twiddle powers out of the unit loop's invariants, and the compiler then
+    # contracts a few multiply-adds the other way round: its results differ from the other two forms in the last bit (3e-16 of
+    # max|X| forward, 1.3e-15 after the inverse; profiles/r03/experiments/lazy_vs_eager_bits.log), are just as close to the
+    # reference, and are the same from run to run and from plan to plan.
+    assert torch.equal(outs["lazy"][0], outs["lazy2"][0]) and torch.equal(outs["lazy"][1], outs["lazy2"][1])
+    for k in (0, 1):
+        assert ((outs["lazy"][k] - outs["0"][k]).abs().max() / outs["0"][k].abs().max()).item() < 1e-14
     ref = so.fftn_reference(x, 1)[0]
-    got = outs["1"][0].cpu().numpy().reshape(ref.shape)
-    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
-    assert (outs["1"][1] / n - a).abs().max().item() < 1e-11
+    for mode in ("1", "lazy"):
+        got = outs[mode][0].cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
+        assert (outs[mode][1] / n - a).abs().max().item() < 1e-11
 
 
 @pytest.mark.parametrize("rot", ["0", "1"])

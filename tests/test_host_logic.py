@@ -305,3 +305,10 @@ def test_headline_kernels_do_not_spill():
             # tile pair outside the point loops (12 bytes; 32 x 16-byte points + the staged store sit exactly at 256 registers)
             allowed = 16 if (tag.startswith("pair") and "DualTiles" in tag) else 0
             assert scratch <= allowed, f"{tag}: {scratch} bytes of scratch"
+    # the one-launch YZ stage (csrc/dfft_zy.hip; the headline's t0): every instantiation, and the lazy-publish kernels with room to
+    # spare (they keep the products of their twiddle powers out of the unit loop's invariants: 192-200 registers)
+    rows = kr.zy_table()
+    assert len(rows) == 24, len(rows)
+    for tag, vgpr, scratch, _ in rows:
+        assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
+        assert vgpr <= (224 if tag.endswith("lazy") else 256), f"{tag}: {vgpr} registers"

@@ -1,0 +1,21 @@
+R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
+ROUND=r03
+OUT=$R/gpurun_out/$ROUND; mkdir -p $OUT
+cd $R
+PROFILE_SKIP_NOCHUNK=1 timeout 200 bash tools/profile_bench.sh $ROUND > $OUT/profile_bench.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+P=$R/gpurun_out/prof_$ROUND
+BENCH2="python $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-pmc"
+timeout 60 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $P/pass_sq -- $BENCH2 > $P/pass_sq.log 2>&1
+timeout 60 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_LEVEL_sum --output-format csv -d $P/pass_ea -- $BENCH2 > $P/pass_ea.log 2>&1
+timeout 60 rocprofv3 --kernel-trace --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum --output-format csv -d $P/pass_tcp -- $BENCH2 > $P/pass_tcp.log 2>&1
+timeout 60 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum TCC_EA0_WRREQ_STALL_sum --output-format csv -d $P/pass_tcc -- $BENCH2 > $P/pass_tcc.log 2>&1
+python $R/tools/pmc_summary.py $P 1000000 zy_chunk_kernel > $OUT/pmc_zy_kernel.txt 2>&1
+python $R/tools/pmc_summary.py $P 1000000 TuneTransposedStore > $OUT/pmc_x_kernel.txt 2>&1
+find $P -name "*.db" -delete; find $P -name "*kernel_trace.csv" -size +20M -delete
+cd $R
+timeout 150 python tools/sweep_bench.py 3d > $OUT/sweep_3d.csv 2> /dev/null
+timeout 90 python tools/long_axis_bench.py > $OUT/long_axis_kernels.csv 2> /dev/null
+timeout 150 bash tools/tune_check.sh $OUT/tune_check_final.log 6 > /dev/null 2>&1
+timeout 120 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
+du -sh $OUT $P; cat $OUT/tune_check_final.log | cut -c1-100; tail -3 $OUT/profile_bench.log

@@ -2,6 +2,7 @@
 csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* directives of every fft_tiles_kernel / fft_dual_tiles_kernel.
 
   python tools/kernel_resources.py <group> [filter]        e.g.  python tools/kernel_resources.py 3 N=512
+  python tools/kernel_resources.py zy                      the kernels of the one-launch YZ stage (csrc/dfft_zy.hip)
 
 A kernel that spills (scratch > 0) or loses occupancy shows up here long before it shows up in a benchmark: the 16- and
 24-point-per-thread column kernels sit within a few registers of the 256-VGPR budget of a 512-thread block."""
@@ -58,9 +59,38 @@ def kernel_table(group: int):
     return rows
 
 
+def zy_table():
+    """[(tag, vgprs, scratch bytes, static LDS bytes)] of the one-launch YZ stage's kernels (csrc/dfft_zy.hip)."""
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+               "-c", str(CSRC / "dfft_zy.hip"), "-o", "zy.o", "-save-temps"]
+        cmd += os.environ.get("DFFT_KR_FLAGS", "").split()
+        r = subprocess.run(cmd, cwd=tmp, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-3000:])
+        asm = next(Path(tmp).glob("*gfx950.s")).read_text()
+    rows = []
+    for m in re.finditer(r"^(_ZN4dfft\w*zy_chunk_kernel\w+): ", asm, re.M):
+        name = m.group(1)
+        body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
+        lens = re.findall(r"ILi(\d+)ELi8E", name)  # Plan<N, 8, ...> of the Z and (when different) Y axis
+        mm = re.search(r"Li(n?1)ELb([01])ELb([01])E", name)
+        if not lens or not mm:
+            continue
+        nz, ny = lens[0], lens[-1]
+
+        def field(key):
+            f = re.search(rf"\.amdhsa_{key} (\d+)", body)
+            return int(f.group(1)) if f else 0
+        tag = (f"f64 zy_chunk_kernel Z={nz} Y={ny} dir={'-1' if mm.group(1) == 'n1' else '1'} packed={mm.group(2)} "
+               f"{'lazy' if mm.group(3) == '1' else 'eager'}")
+        rows.append((tag, field("next_free_vgpr"), field("private_segment_fixed_size"), field("group_segment_fixed_size")))
+    return rows
+
+
 if __name__ == "__main__":
-    g = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
-    for tag, vgpr, scratch, lds in kernel_table(g):
+    rows = zy_table() if len(sys.argv) > 1 and sys.argv[1] == "zy" else kernel_table(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
+    for tag, vgpr, scratch, lds in rows:
         if flt in tag:
             print(f"{tag:<70} vgpr {vgpr:>3}  scratch {scratch:>4} B")
