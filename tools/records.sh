@@ -3,8 +3,11 @@
 #   tools/records.sh [round, default r03]
 # 1. rocprofv3 kernel trace + stats and FETCH_SIZE / WRITE_SIZE passes of the graded bench command (tools/profile_bench.sh)
 # 2. two more counter passes (SQ wave-state counters; fabric request counts and queue levels) on the same command
-# 3. 3D sweep, long-axis kernels, the reference's batched component benchmarks, per-rank local work by P, tuning check
+# 3. 3D sweep, long-axis kernels, the reference's batched component benchmarks, per-rank local work by P, tuning check,
+#    the bench line with the driver's arguments (CPU leg included), the full -m gpu suite
+# RECORDS_SKIP="batch local pytest": leave those parts out (a refresh after a kernel change that does not touch them)
 ROUND=${1:-r03}
+skip() { case " $RECORDS_SKIP " in *" $1 "*) return 0;; esac; return 1; }
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 OUT=$R/gpurun_out/$ROUND; mkdir -p $OUT
 cd $R
@@ -22,9 +25,13 @@ find $P -name "*.db" -delete; find $P -name "*kernel_trace.csv" -size +20M -dele
 cd $R
 python tools/sweep_bench.py 3d > $OUT/sweep_3d.csv 2> /dev/null
 python tools/long_axis_bench.py > $OUT/long_axis_kernels.csv 2> /dev/null
-NUM_ITER=100 bash tools/run_batch_tests.sh $OUT > /dev/null 2>&1
+bash tools/tune_check.sh $OUT/tune_check_final.log 6 > /dev/null 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_driver_args.err
+skip pytest || python -m pytest tests -m gpu -q > $OUT/pytest_gpu_full.log 2>&1
+if ! skip local; then
 python tools/local_by_P.py 512x512x512 fp64 4 2>&1 | grep -v amdgpu.ids > $OUT/local_by_P.log
 python tools/local_by_P.py 1024x768x512 fp64 3 2>&1 | grep -v amdgpu.ids >> $OUT/local_by_P.log
 python tools/local_by_P.py 2048x2048x1024 fp32 2 2>&1 | grep -v amdgpu.ids >> $OUT/local_by_P.log
-bash tools/tune_check.sh $OUT/tune_check_final.log 6 > /dev/null 2>&1
+fi
+skip batch || NUM_ITER=100 bash tools/run_batch_tests.sh $OUT > /dev/null 2>&1
 du -sh $OUT $P
