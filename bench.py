@@ -165,6 +165,7 @@ def live_traffic(args, nchunks: int):
     is not there, a pass fails or takes too long -- the committed figure is the fall-back then."""
     import csv
     import glob
+    import re
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3")
@@ -190,7 +191,7 @@ def live_traffic(args, nchunks: int):
                     continue
                 if "TuneTransposedStore" in name and ", 1, false" in name:
                     x.append(val)                      # forward X pass (the tuning's probe launches move the same bytes)
-                elif "zy_chunk_kernel" in name and ", 1>" in name:
+                elif "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*>", name):  # forward one-launch YZ stage (any variant)
                     zy.append(val)
                 elif ", 1, false, dfft::TuneStreamIn>" in name:
                     rows_.append(val)                  # forward Z rows, one launch per cache chunk
