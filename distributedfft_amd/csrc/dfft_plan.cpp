@@ -230,7 +230,7 @@ struct dfft_plan_s {
     bool                    zy_on = false;
     unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
-    bool                    zy_lazy = false;           // DFFT_ZY_LAZY=1 when the plan was created: lazy-publish variant of the kernel
+    bool                    zy_lazy = false;           // lazy-publish form of the one-launch kernel (un-packed launches; DFFT_ZY_LAZY=0: eager)
     int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.

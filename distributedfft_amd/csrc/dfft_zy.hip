@@ -10,17 +10,21 @@
 // inside the stage (the phases overlap at their edges instead of draining the GPU): 1.365 -> 1.337 ms in the experiment that
 // preceded this file.  The inverse transform runs the mirror image (column units first, then row units into the result buffer).
 //
-// The arithmetic is the library's own (run_stages of dfft_fft_impl.h with the same plans and register twiddles), so results are
-// bit-identical to the two-launch path -- tests/test_gpu_parity.py::test_one_launch_t0_is_bit_identical.
+// The arithmetic is the library's own (run_stages of dfft_fft_impl.h with the same plans and register twiddles): the eager-publish
+// kernel is bit-identical to the two-launch path, the lazy-publish one (the default for single-GPU plans, see LAZY below) agrees
+// with it to the last bit or two and is deterministic -- tests/test_gpu_parity.py::test_one_launch_t0_is_bit_identical.
 //
 // Deadlock freedom: tickets are taken in order by RUNNING workgroups only; a producer unit never waits; a consumer unit waits only
-// for producer units with smaller tickets, and a workgroup never holds an unprocessed item while it waits (the next item is
-// prefetched only if its dependency is already satisfied).  Every spin is bounded by the wall clock; a time-out sets ctl->error,
-// every workgroup leaves, and the host reports it at the next synchronisation (and goes back to the two-launch path).
+// for producer units with smaller tickets, and a workgroup never holds an unprocessed item -- nor, in the lazy form, an unpublished
+// producer unit -- while it waits (the next item is prefetched only if its dependency is already satisfied).  Every spin is bounded
+// by the wall clock; a time-out sets ctl->error, every workgroup leaves, and the host reports it at the next synchronisation (and
+// goes back to the two-launch path).
 //
 // Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes); single-GPU fused
 // plans (hand-over buffer or bufferDev1 as w) and P > 1 fused plans with even splits (the Y side then reads / writes the packed,
 // row-rotated exchange layout), whole slabs or the X-plane parts of the overlapped pipeline.  Everything else keeps the chunk loop.
+// The plan uses the stage by itself for 512 x 512-point planes only: with a 256-point axis in the plane two launches per chunk are
+// faster (dfft_plan.cpp, profiles/r03/experiments/variant_ab_256.log).
 #include "dfft_fft_impl.h"
 #include "dfft_zy.h"
 
@@ -35,7 +39,7 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 // DIR = -1: producers = Y columns (w in place), consumers = Z rows (w -> dst)
 // PACK: the column side that is not w is the packed exchange layout of a P > 1 plan (forward: Y columns w -> packed send buffer,
 // backward: packed receive buffer -> w) described by the launcher's axis map `pk`, with the rows rotated per plane (RotMap mode 1)
-// LAZY (measurement variant, DFFT_ZY_LAZY=1): gfx9 counts loads and stores in one vmcnt, so "wait for the prefetched unit" after a
+// LAZY (un-packed launches; the plan's default, DFFT_ZY_LAZY=0 selects the eager form): gfx9 counts loads and stores in one vmcnt, so "wait for the prefetched unit" after a
 // unit's stores have been issued means "drain those stores" -- and a producer unit drains them again before it publishes.  The lazy
 // form waits for everything that is in flight (the previous unit's stores, the next unit's loads) after a unit's ARITHMETIC, when
 // it has had a whole unit's exchanges to complete, publishes the PREVIOUS producer unit there, and only then issues this unit's
