@@ -88,8 +88,10 @@ struct TuneTransposedStore {
 };
 // The same kernel for 16 points per thread (1024-point X pass) with a WHOLE second register set.  What made room: the input side
 // of the X pass is a single-block map (plane stride x FFT index), so the 16 per-point load offsets become one register plus
-// k * step with a wave-uniform step (PLAIN_IN), and the staged store's offsets were affine already -- 228 (half prefetch) ->
-// 25x VGPRs, no scratch (profiles/r03/kernel_resources.txt).  Why it matters: gfx9 counts loads and stores in ONE vmcnt, and with
+// k * step with a wave-uniform step (PLAIN_IN; kept out of the tile loop's invariants, see load_part), and the staged store's
+// offsets were affine already -- 228 VGPRs like the half prefetch, 246 with rotated rows, no scratch
+// (profiles/r03/kernel_resources.txt).  Measured: fp32 pairs 4.95 -> 5.47 TB/s, the rotated P = 8 form 4.41 -> 4.67, fp64 at
+// P = 1 4.62 -> 4.68 (profiles/r03/experiments/variant_ab.log).  Why it matters: gfx9 counts loads and stores in ONE vmcnt, and with
 // both kinds outstanding the compiler has to wait for all of them, so a tile's exposed memory phases are what is NOT in flight
 // underneath its exchanges -- the half prefetch left two such phases per tile (the second half of the loads, then the stores)
 // and gained nothing in fp64 (profiles/r03/experiments/half_prefetch_ab.log); with the whole next tile in flight underneath the
@@ -587,9 +589,10 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     auto load_tile = [&](unsigned t, V* dst) { load_part(t, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}); };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
     constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH) && KG::THREADS <= 512;
-    // 16 points per thread (1024- and 2048-point columns): a whole second register set does not fit (64 VGPRs: 4.6 -> 3.7 TB/s,
-    // round 1), but the kernels leave room for HALF of one -- the first 8 points of the next tile are fetched underneath the
-    // current tile's exchanges and stores, the other 8 at the top of the next iteration.  DFFT_HALF_PREFETCH=0 compiles it out.
+    // 16 points per thread (1024- and 2048-point columns) without Tune::FULL_PREFETCH: a whole second register set does not fit next
+    // to per-point offsets (64 VGPRs: 4.6 -> 3.7 TB/s, round 1), but the kernels leave room for HALF of one -- the first 8 points of
+    // the next tile are fetched underneath the current tile's exchanges and stores, the other 8 at the top of the next iteration.
+    // DFFT_HALF_PREFETCH=0 compiles it out.
 #ifndef DFFT_HALF_PREFETCH
 #define DFFT_HALF_PREFETCH 1
 #endif
