@@ -117,6 +117,15 @@ struct TuneCols : TuneDefault {
     static constexpr bool PREFETCH = true;
 };
 
+// Column kernels whose two sides are single-block maps (single-GPU plans, the 1-D column API, the backward X pass): every offset
+// is base + k * step with wave-uniform steps (PLAIN), and -- as in TuneTransposedStoreFull -- the per-point values are kept out of
+// the tile loop's invariants, where the compiler would otherwise park 2 E of them in registers.  Instantiated for the lengths whose
+// column kernels spilled with per-point offsets: 1280 (20 points per thread) 68 -> 0 B at 202 VGPRs, 1536 (24) 92 -> 0 B at 198,
+// 1000 (800-thread blocks, 128-VGPR budget) 164 -> 24 B (profiles/r03/kernel_resources.txt).
+template <class Base> struct Plain : Base {
+    static constexpr bool PLAIN = true;
+};
+
 // Cache-policy variants for the Infinity-Cache-blocked Z+Y stage (execute_forward/backward in dfft_plan.cpp).
 struct TuneStreamIn : TuneDefault {
     static constexpr bool NTL = true;
@@ -572,7 +581,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         int      rj = rot_j;
         unsigned ir0 = irel[0];
         if constexpr (Tune::ROT_IN == 2 && Tune::PLAIN_IN) asm volatile("" : "+v"(rj));
-        if constexpr (Tune::PLAIN_IN) asm volatile("" : "+v"(ir0));
+        if constexpr (PLAIN_IN) asm volatile("" : "+v"(ir0));
         if (ok) {
 #pragma unroll
             for (int k = K0; k < K1; ++k) {
@@ -692,9 +701,11 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 #pragma unroll
                 for (int k = 0; k < PF; ++k) pin_loaded(vnext[k]);
             }
+            unsigned or0 = orel[0];
+            if constexpr (PLAIN) asm volatile("" : "+v"(or0));  // per tile, not a loop invariant (see load_part)
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                long long off = PLAIN ? (long long)(orel[0] + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
+                long long off = PLAIN ? (long long)(or0 + (unsigned)k * ostep) : (long long)orel[PLAIN ? 0 : k];
                 if (GENERAL) off += ((olast >> k) & 1u) ? (long long)a * omap.last_delta : 0ll;
                 if constexpr (Tune::ROT_OUT == 2) off += (long long)(((ob0 + rot_j + k * rot_t) & rm.mask) - ob0);
                 gstore<Tune::NTS>(op + off, VT::to_g(cscale(v[k], sc)));
@@ -1242,6 +1253,20 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneCols, 1, 0>>(L, stream);
             }
             return hipErrorInvalidValue;
+        }
+        // single-block maps on both sides: the PLAIN twins of the column variants, for the lengths that need the registers
+        constexpr bool can_plain = P::N == 1000 || P::N == 1280 || P::N == 1536;
+        if constexpr (can_plain) {
+            const bool single = L.imap.nblk == 1 && L.imap.sub <= 1 && L.omap.nblk == 1 && L.omap.sub <= 1;
+            const bool is_staged = can_stage && staged;
+            if (!general && single && !is_staged) {
+                if (L.dir > 0) {
+                    if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, Plain<TuneColsStreamOut>>(L, stream);
+                    return launch_variant<V, P, CBC, GC, +1, false, Plain<TuneCols>>(L, stream);
+                }
+                if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneColsStreamIn>>(L, stream);
+                return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneCols>>(L, stream);
+            }
         }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);
