@@ -170,10 +170,21 @@ constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 
 #endif
 template <class P> constexpr bool tw_sharing() { return DFFT_TW_EFFECTIVE || P::N >= 4096; }
 
+// DFFT_TW_STAGE_MAJOR=1 (build-time experiment, not yet measured -- prepared at the end of round 3 without GPU time left): the LDS
+// copy of the twiddle table (TW_LDS kernels: 16 points per thread, 1024 / 2048 points) is laid out [stage][m][r - 1] like the
+// reference's LUT (templateFFT.cpp:5120-5141) instead of as the natural N-entry table read at r * m * N / (Ns R).  In the early
+// stages (small Ns) the lanes of a ds_read_b128 group read a handful of distinct entries a power-of-two number of bytes apart --
+// the same banks, 2-4-way conflicts on R - 1 reads per butterfly (SQ_LDS_BANK_CONFLICT 9-36 % of these kernels' LDS cycles,
+// profiles/r03/experiments/lds_bank_conflicts_long_x_pass.log); stage-major they are consecutive.  Same values, so results must be
+// bit-identical to the default build.  Entries: sum over stages s >= 1 of Ns (R - 1) = N - R_0 <= N: the same LDS area.
+#ifndef DFFT_TW_STAGE_MAJOR
+#define DFFT_TW_STAGE_MAJOR 0
+#endif
 template <class P, int S, bool TWPOW> struct StageInfo {
     using Prev = StageInfo<P, S - 1, TWPOW>;
     static constexpr int R = P::R[S];
     static constexpr int NS = Prev::NS * Prev::R;
+    static constexpr int SM_OFF = Prev::SM_OFF + (S > 1 ? Prev::NS * (Prev::R - 1) : 0);  // stage-major LDS table: first entry of stage S
     static constexpr int B = P::E / R;
     static constexpr int SLOTS = tw_slots(R, TWPOW);
     static constexpr bool SHARED = tw_sharing<P>() && (P::T % NS == 0);  // one set for all B butterflies
@@ -184,6 +195,7 @@ template <class P, int S, bool TWPOW> struct StageInfo {
 template <class P, bool TWPOW> struct StageInfo<P, 0, TWPOW> {
     static constexpr int R = P::R[0];
     static constexpr int NS = 1;
+    static constexpr int SM_OFF = 0;
     static constexpr int B = P::E / R;
     static constexpr int SLOTS = 0;
     static constexpr bool SHARED = false;
@@ -237,6 +249,22 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
     }
 }
 
+// LDS copy of the twiddle table for TW_LDS kernels in stage-major order (DFFT_TW_STAGE_MAJOR builds only)
+template <class W, class P, int S, int DIR> __device__ __forceinline__ void fill_stage_major(W* dst, const W* __restrict__ tw, int tid, int threads) {
+    if constexpr (S < P::S) {
+        using SI = StageInfo<P, S, false>;
+        if constexpr (S > 0) {
+            constexpr int R = SI::R, NS = SI::NS, CNT = NS * (R - 1), STRIDE = P::N / (NS * R);
+            for (int i = tid; i < CNT; i += threads) {
+                const int m = i / (R - 1), r = i % (R - 1) + 1;
+                W w = tw[r * m * STRIDE];
+                if (DIR < 0) w.y = -w.y;
+                dst[SI::SM_OFF + i] = w;
+            }
+        }
+        fill_stage_major<W, P, S + 1, DIR>(dst, tw, tid, threads);
+    }
+}
 // TWMODE: where a stage finds its twiddles.
 //   TW_REG    per-thread set preloaded into VGPRs
 //   TW_LDS    direction-adjusted N-entry table staged in LDS once per block
@@ -258,6 +286,13 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
 #pragma unroll
         for (int r = 0; r < R; ++r) u[r] = v[q + r * B];
         if constexpr (S > 0) {
+#if DFFT_TW_STAGE_MAJOR
+            if constexpr (TWMODE == TW_LDS && TWS == 1) {
+                const W* ts = twr + SI::SM_OFF + ((j + q * T) % NS) * (R - 1);
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], ts[r - 1]);
+            } else
+#endif
             if constexpr (TWMODE == TW_LDS) {
                 const int m = ((j + q * T) % NS) * (TWS * P::N / (NS * R));
 #pragma unroll
@@ -480,11 +515,15 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     if constexpr (KG::TWMODE == TW_GLOBAL) {
         twr = tw;
     } else if constexpr (KG::TWMODE == TW_LDS) {
+#if DFFT_TW_STAGE_MAJOR
+        fill_stage_major<W, P, 0, DIR>(ldstw, tw, (int)threadIdx.x, KG::THREADS);
+#else
         for (int i = threadIdx.x; i < N; i += KG::THREADS) {
             W w = tw[i];
             if (DIR < 0) w.y = -w.y;
             ldstw[i] = w;
         }
+#endif
         __syncthreads();
         twr = ldstw;
     } else {
@@ -761,11 +800,15 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     W* ldstw = reinterpret_cast<W*>(dfft_smem);
     V* lds = reinterpret_cast<V*>(dfft_smem + TW_BYTES);
     const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+#if DFFT_TW_STAGE_MAJOR
+    fill_stage_major<W, P, 0, DIR>(ldstw, tw, tid, GT);
+#else
     for (int i = tid; i < N; i += GT) {
         W w = tw[i];
         if (DIR < 0) w.y = -w.y;
         ldstw[i] = w;
     }
+#endif
     __syncthreads();
     // The launcher guarantees imap.blk % T == 0: the block a point j + T*k falls into depends on k alone, so its
     // offset splits into a wave-uniform term per k and ONE per-thread term -- no per-point address registers next to the two
