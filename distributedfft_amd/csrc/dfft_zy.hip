@@ -392,8 +392,20 @@ unsigned zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk)
 
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
+// DFFT_ZY_LAZY_PACKED=1 (build-time experiment, not yet run): the lazy-publish form for the packed P > 1 launches too (opt-in plans,
+// DFFT_T0_ONE_LAUNCH=all; its results will differ from the two-launch path in the last bit like the un-packed form's)
+#ifndef DFFT_ZY_LAZY_PACKED
+#define DFFT_ZY_LAZY_PACKED 0
+#endif
+#if DFFT_ZY_LAZY_PACKED
+#define DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_) \
+    if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream);
+#else
+#define DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_)
+#endif
 #define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
+        DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_)                                                                                      \
         if (L.lazy && !L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
         if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \
         return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false>(L, stream) : launch_zy_t<PZ_, PY_, -1, false>(L, stream);            \
