@@ -11,9 +11,11 @@ bool long_split(long long n, int* n1, int* n2);
 int long_fft(const void* in, void* out, long long n, long long s, long long batch, int dtype, int dir, double scale, void* scratch,
              hipStream_t stream);
 // scratch for callers without a plan (dfft_fft1d_rows / dfft_fft1d_cols): a grow-only buffer per (device, stream), leased to one
-// host thread at a time -- long_scratch() takes the lease, long_scratch_release() returns it after the work has been enqueued
-void* long_scratch(size_t bytes, hipStream_t stream);
-void  long_scratch_release(void* p, hipStream_t stream);
-void  long_scratch_trim();  // frees every cached buffer that is not leased (dfft_trim)
+// host thread at a time -- long_scratch() takes the lease (nullptr buffer: nothing leased), long_scratch_release() returns it after
+// the work has been enqueued.  The lease is self-contained: releasing it cannot fail and does not depend on the current device.
+typedef void* LongScratchLease;
+void* long_scratch(size_t bytes, hipStream_t stream, LongScratchLease* lease);
+void  long_scratch_release(LongScratchLease lease);
+void  long_scratch_trim();  // frees every cached buffer that is not leased (dfft_trim); drains the owning devices first
 
 }  // namespace dfft

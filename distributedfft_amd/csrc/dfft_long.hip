@@ -195,21 +195,29 @@ bool long_split(long long n, int* n1, int* n2) {
 // long_scratch() until long_scratch_release(), i.e. across the caller's enqueue: a second host thread on the same stream waits
 // for the first one's kernels to be queued, and when it has to grow the buffer its hipStreamSynchronize covers them before the
 // old buffer is freed.  (hipMallocAsync / hipFreeAsync per call was tried first and gave wrong results on the NULL stream.)
+// The lease IS the entry: release needs no look-up (nothing that can fail or find another entry because the calling thread's
+// current device changed in between), so a lease that was taken is always returned.
 struct ScratchEntry {
     std::mutex m;
     void*      p = nullptr;
     size_t     bytes = 0;
+    int        dev = 0;
 };
 static std::map<std::pair<int, hipStream_t>, std::unique_ptr<ScratchEntry>> g_scratch;
 
-void* long_scratch(size_t bytes, hipStream_t stream) {
+void* long_scratch(size_t bytes, hipStream_t stream, LongScratchLease* lease) {
+    if (!lease) return nullptr;
+    *lease = nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     ScratchEntry* e = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mutex);
         auto&                       slot = g_scratch[std::make_pair(dev, stream)];
-        if (!slot) slot.reset(new ScratchEntry);
+        if (!slot) {
+            slot.reset(new ScratchEntry);
+            slot->dev = dev;
+        }
         e = slot.get();
     }
     e->m.lock();
@@ -228,33 +236,38 @@ void* long_scratch(size_t bytes, hipStream_t stream) {
         }
         e->bytes = bytes;
     }
+    *lease = e;
     return e->p;
 }
-void long_scratch_release(void* p, hipStream_t stream) {
-    if (!p) return;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return;
-    ScratchEntry* e = nullptr;
+void long_scratch_release(LongScratchLease lease) {
+    if (lease) static_cast<ScratchEntry*>(lease)->m.unlock();
+}
+// Frees every cached buffer that is not leased.  The cached stream handles belong to callers and may have been destroyed since, so
+// they are not touched: the owning device is drained instead, and neither that wait nor the frees run under the registry lock
+// (entries are never removed from the registry, so the pointers collected under it stay valid).
+void long_scratch_trim() {
+    std::vector<ScratchEntry*> entries;
     {
         std::lock_guard<std::mutex> lk(g_mutex);
-        auto                        it = g_scratch.find(std::make_pair(dev, stream));
-        if (it != g_scratch.end()) e = it->second.get();
+        for (auto& kv : g_scratch) entries.push_back(kv.second.get());
     }
-    if (e && e->p == p) e->m.unlock();
-}
-void long_scratch_trim() {
-    std::lock_guard<std::mutex> lk(g_mutex);
-    for (auto& kv : g_scratch) {
-        ScratchEntry* e = kv.second.get();
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (ScratchEntry* e : entries) {
         if (!e->m.try_lock()) continue;  // in use right now
         if (e->p) {
-            (void)hipStreamSynchronize(kv.first.second);
-            (void)hipFree(e->p);
+            if (hipSetDevice(e->dev) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(e->p);
+                e->p = nullptr;
+                e->bytes = 0;
+            } else {
+                (void)hipGetLastError();
+            }
         }
-        e->p = nullptr;
-        e->bytes = 0;
         e->m.unlock();
     }
+    if (have_cur) (void)hipSetDevice(cur);
 }
 
 int long_fft(const void* in, void* out, long long n, long long s, long long batch, int dtype, int dir, double scale, void* scratch,

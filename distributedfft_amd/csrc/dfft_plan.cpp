@@ -133,10 +133,11 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
         const size_t off = (size_t)first_row * n * elem_bytes(dtype);
         void*        scr = long_scratch_buf ? long_scratch_buf : t_plan_scratch;
         const bool   own = !scr;
-        if (own) scr = long_scratch((size_t)rows * n * elem_bytes(dtype), s);
+        LongScratchLease lease = nullptr;
+        if (own) scr = long_scratch((size_t)rows * n * elem_bytes(dtype), s, &lease);
         if (!scr) return fail(DFFT_EHIP, "fft_rows: cannot allocate the scratch buffer of the four-step transform");
         const int rc = long_fft((const char*)in + off, (char*)out + off, n, 1, rows, dtype, dir, scale, scr, s);
-        if (own) long_scratch_release(scr, s);
+        long_scratch_release(lease);
         return rc;
     }
     const void* tw = nullptr;
@@ -227,6 +228,10 @@ struct dfft_plan_s {
     // t0 as one persistent launch (dfft_zy.hip) instead of two launches per cache chunk: single-GPU fused plans in fp64 whose Y and
     // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
     ZyCtl*                  zy_ctl = nullptr;
+    unsigned*               zy_err = nullptr;   // pinned host word the kernel writes ZY_ERR_* to when it gives up (read without a copy)
+    unsigned                zy_spin_polls = 0;  // bound of a consumer unit's wait (polls; DFFT_ZY_SPIN_POLLS)
+    int                     zy_fault = 0;       // DFFT_ZY_FAULT=n (test hook): launch number n of the stage waits for producers that never come
+    unsigned                zy_launches = 0;
     bool                    zy_on = false;
     unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
@@ -484,6 +489,8 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.twz = twz;
     L.twy = twy;
     L.lazy = p->zy_lazy ? 1 : 0;
+    L.spin_polls = p->zy_spin_polls;
+    if (hipHostGetDevicePointer((void**)&L.err_host, p->zy_err, 0) != hipSuccess) return fail(DFFT_EHIP, "one-launch YZ stage: no device pointer for the error word");
     if (packed) {
         TileMap tile;
         packed_map(p, &L.pk, &tile);
@@ -504,19 +511,26 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     if (x0 == 0) p->zy_cur = p->zy_execs++;
     L.ticket_base = p->zy_ticket;
     L.done_base = p->zy_cur * producers;
+    if (p->zy_fault > 0 && ++p->zy_launches == (unsigned)p->zy_fault) ++L.done_base;  // test hook: this launch's consumers can never start
     p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.nplanes, L.chunk);
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
 }
 
-// after the plan's stream has drained: did a one-launch stage give up (a consumer waited > 20 ms for its producers)?
+// Did a launch of the one-launch stage give up (a consumer unit exhausted its polls, or a launch found the control block's counters
+// out of step)?  The kernel writes the reason to a pinned host word, so this costs one host load and can run anywhere -- before
+// an execute is queued, after a drained one, in sync / stage_times / destroy.  The word is sticky on the device side (every later
+// launch on the block returns at once), so nothing computed after the failure can pass for a result; the stage is switched off for
+// good here and the plan continues on two launches per chunk.
 static int zy_check(dfft_plan_s* p) {
-    if (!p->zy_on || !p->zy_ctl) return DFFT_OK;
-    unsigned err = 0;
-    DFFT_HIP_TRY(hipMemcpy(&err, &p->zy_ctl->error, sizeof(err), hipMemcpyDeviceToHost));
+    if (!p->zy_on || !p->zy_err) return DFFT_OK;
+    const unsigned err = *(volatile unsigned*)p->zy_err;
     if (err == 0) return DFFT_OK;
     p->zy_on = false;  // two launches per chunk from now on
-    return fail(DFFT_EHIP, "the one-launch YZ stage timed out waiting for its own producers; the result of that execute is invalid, "
-                           "later executes of this plan use the two-launch stage (DFFT_T0_ONE_LAUNCH=0 selects it from the start)");
+    return fail(DFFT_EHIP, std::string("the one-launch YZ stage gave up (") +
+                               (err == ZY_ERR_TIMEOUT ? "a column / row unit exhausted its polls waiting for its plane's producers"
+                                                      : "its ticket counter was out of step with the host's") +
+                               "); the results of that execute and of every execute queued behind it are invalid, later executes of this plan "
+                               "use the two-launch stage (DFFT_T0_ONE_LAUNCH=0 selects it from the start)");
 }
 
 static int execute_forward(dfft_plan_s* p, bool sync) {
@@ -1188,10 +1202,18 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test
             // suite, on recycled memory)
             if (hipMalloc((void**)&p->zy_ctl, sizeof(ZyCtl)) == hipSuccess && hipMemsetAsync(p->zy_ctl, 0, sizeof(ZyCtl), p->stream) == hipSuccess &&
-                hipStreamSynchronize(p->stream) == hipSuccess)
+                hipStreamSynchronize(p->stream) == hipSuccess && hipHostMalloc((void**)&p->zy_err, 128, hipHostMallocMapped) == hipSuccess) {
+                *p->zy_err = 0u;
                 p->zy_on = true;
-            else
+                // a consumer's wait is bounded in polls (1-3 us each under load): seconds by default, so that time-slicing with
+                // other processes, a profiler or a debugger cannot produce a spurious time-out, while a real dead-lock still ends
+                const char* sp = getenv("DFFT_ZY_SPIN_POLLS");
+                p->zy_spin_polls = sp && atoll(sp) > 0 ? (unsigned)std::min(atoll(sp), 0xffffffffll) : (4u << 20);
+                const char* fe = getenv("DFFT_ZY_FAULT");
+                p->zy_fault = fe ? atoi(fe) : 0;
+            } else {
                 (void)hipGetLastError();
+            }
         }
     }
     {
@@ -1266,12 +1288,38 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     plan->host_timed = sync;
     plan->timed = sync || !(exec_flags & DFFT_EXEC_NO_TIMING);
     if (!plan->timed && (exec_flags & DFFT_EXEC_PRINT)) return fail(DFFT_EINVAL, "dfft_execute: PRINT needs stage timing");
-    t_plan_scratch = plan->lbuf;
-    int rc = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
-             : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
-                                               : execute_backward(plan, sync);
-    t_plan_scratch = nullptr;
+    // an earlier execute of the one-launch YZ stage that gave up and that nobody synchronised through the library (the pinned error
+    // word is readable at any time): report it before anything else is queued; the stage is off from here on
+    {
+        const int zrc = zy_check(plan);
+        if (zrc) return zrc;
+    }
+    auto run = [&]() {
+        t_plan_scratch = plan->lbuf;
+        const int r = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
+                      : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
+                                                        : execute_backward(plan, sync);
+        t_plan_scratch = nullptr;
+        return r;
+    };
+    const bool zy_used = plan->zy_on;
+    int        rc = run();
     if (rc) return rc;
+    // host-synchronised executes have drained the stream (the reference-named wrapper always executes this way): a one-launch YZ
+    // stage that gave up is seen here, before any timing is printed or any result used.  Where the pipeline has not written its own
+    // input -- fused single-GPU plans that read `in` or bufferDev1 and work in the hand-over buffer -- the transform is simply run
+    // again on two launches per chunk (zy_check has switched the stage off); otherwise the failure is the return code.
+    if (sync && zy_used) {
+        rc = zy_check(plan);
+        if (rc) {
+            const void* src = (plan->flags & DFFT_PLAN_INPUT_FROM_IN) ? plan->in : plan->buf1;
+            const bool  input_intact = !plan->exch && plan->wbuf && src != plan->buf2 && !(plan->flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL));
+            if (!input_intact) return rc;
+            if (getenv("DFFT_DEBUG")) fprintf(stderr, "[dfft] %s -- running the transform again on the two-launch stage\n", dfft_last_error());
+            rc = run();
+            if (rc) return rc;
+        }
+    }
     // host-synchronised executes have drained the stream: an asynchronous exchange that timed out on a dead or slow peer
     // must not let the caller print timings / use results (the reference-named wrapper always executes this way)
     if (sync && plan->comm) {
@@ -1338,7 +1386,7 @@ int dfft_plan_tune(dfft_plan_t plan) {
     // behaviours are 5-8 % apart), after DFFT_TUNE_TRIES candidates (default 128), or when the transient footprint would exceed
     // 70 % of the free device memory; one probe costs about 7 X passes.  DFFT_TUNE_SPACER_MB puts a spacer in front of every
     // candidate (coarser, further-reaching walk).
-    int         max_tries = 128;
+    int         max_tries = 32;
     const char* mt = getenv("DFFT_TUNE_TRIES");
     if (mt && atoi(mt) > 0) max_tries = atoi(mt);
     size_t      spacer_bytes = 0;
@@ -1349,15 +1397,47 @@ int dfft_plan_tune(dfft_plan_t plan) {
         (void)hipGetLastError();
         free_b = 0;
     }
-    const size_t budget = free_b / 10 * 7;
+    // transient footprint: at most a quarter of the free device memory by default (DFFT_TUNE_MEM_PCT, 1 ... 90) -- other plans and
+    // processes share the GPU; the fast / slow decision has needed 2-9 candidates in every recorded run (profiles/r03/experiments/
+    // tune_check_*.log)
+    int         pct = 25;
+    const char* pe = getenv("DFFT_TUNE_MEM_PCT");
+    if (pe && atoi(pe) >= 1 && atoi(pe) <= 90) pct = atoi(pe);
+    const size_t budget = free_b / 100 * (size_t)pct;
+    // The probe launches of a forward plan write (garbage) into the plan's result buffer -- the caller's `out`, which the
+    // reference's plan creation never touches (fft_mpi_3d_api.cpp:41-141): its contents are set aside and put back.  Without
+    // room for that copy nothing is tuned.
+    void*        saved_out = nullptr;
+    const size_t out_bytes = (size_t)p->max_count * elem_bytes(p->dtype);
+    if (p->direction == DFFT_FORWARD) {
+        if (out_bytes + wbytes > budget || hipMalloc(&saved_out, out_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return DFFT_OK;
+        }
+        if (hipMemcpyAsync(saved_out, p->buf2, out_bytes, hipMemcpyDeviceToDevice, p->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(saved_out);
+            return DFFT_OK;
+        }
+    }
+    auto restore_out = [&]() {
+        if (!saved_out) return;
+        (void)hipMemcpyAsync(p->buf2, saved_out, out_bytes, hipMemcpyDeviceToDevice, p->stream);
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipFree(saved_out);
+        saved_out = nullptr;
+    };
     std::vector<void*> cand(1, p->wbuf), spacers;
     p->w_ms.clear();
     float ms = 0.f;
     int   rc = probe_x_pass(p, p->wbuf, &ms);
-    if (rc) return rc;
+    if (rc) {
+        restore_out();
+        return rc;
+    }
     p->w_ms.push_back(ms);
     float  lo = ms, hi = ms;
-    size_t used = 0;
+    size_t used = saved_out ? out_bytes : 0;
     while ((int)cand.size() < max_tries && used + spacer_bytes + wbytes <= budget) {
         if (lo < 0.97f * hi) break;  // both behaviours seen: keep the fast one
         void *sp = nullptr, *nw = nullptr;
@@ -1391,9 +1471,13 @@ int dfft_plan_tune(dfft_plan_t plan) {
         if (i != best) (void)slab_free(cand[i]);
     p->wbuf = cand[best];
     p->w_kept = best;
-    if (rc) return rc;
+    if (rc) {
+        restore_out();
+        return rc;
+    }
     // the kept buffer once more, now that its neighbours are gone (reported, not acted upon)
     rc = probe_x_pass(p, p->wbuf, &p->w_final_ms);
+    restore_out();
     if (getenv("DFFT_DEBUG")) {
         fprintf(stderr, "[dfft] hand-over buffer placement: X pass");
         for (float v : p->w_ms) fprintf(stderr, " %.4f", v);
@@ -1468,6 +1552,9 @@ int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
     if (plan->host_timed || !plan->timed)
         return fail(DFFT_EINVAL, "dfft_kernel_times: needs an execute without DFFT_EXEC_SYNC_STAGES / DFFT_EXEC_NO_TIMING");
     if (plan->flags & DFFT_PLAN_UNFUSED) return fail(DFFT_EINVAL, "dfft_kernel_times: fused plans only");
+    if (plan->zy_on)
+        return fail(DFFT_EINVAL, "dfft_kernel_times: not available -- this plan runs its Z and Y passes inside ONE launch (no event between them); "
+                                 "create it with DFFT_T0_ONE_LAUNCH=0 to time the passes separately");
     if (plan->chunk_planes > 0 || plan->part_planes > 0)
         return fail(DFFT_EINVAL, "dfft_kernel_times: Z and Y launches are interleaved per cache chunk (set DFFT_CHUNK_MB=0)");
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
@@ -1491,6 +1578,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (!plan) return DFFT_OK;
     if (plan->stream) hipStreamSynchronize(plan->stream);
     if (plan->stream2) hipStreamSynchronize(plan->stream2);
+    const int zy_rc = zy_check(plan);  // an execute nobody synchronised through the library: its failure is reported here at the latest
     if (plan->comm) {  // same order as the registrations (the IPC communicator makes these collective)
         comm_unregister(plan->comm, plan->me, plan->xd2.slot);
         comm_unregister(plan->comm, plan->me, plan->xd.slot);
@@ -1509,8 +1597,9 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
     if (plan->zy_ctl) hipFree(plan->zy_ctl);
+    if (plan->zy_err) hipHostFree(plan->zy_err);
     delete plan;
-    return DFFT_OK;
+    return zy_rc;
 }
 
 int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype, int direction, void* stream) {
@@ -1543,10 +1632,11 @@ int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long
     if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft1d_cols: no HIP device visible (no CPU fallback)");
     if (n > 4096) {
         if (batch == 0) return DFFT_OK;
-        void* scr = long_scratch((size_t)batch * n * width * elem_bytes(dtype), (hipStream_t)stream);
+        LongScratchLease lease = nullptr;
+        void*            scr = long_scratch((size_t)batch * n * width * elem_bytes(dtype), (hipStream_t)stream, &lease);
         if (!scr) return fail(DFFT_EHIP, "dfft_fft1d_cols: cannot allocate the scratch buffer of the four-step transform");
         const int rc = long_fft(in, out, n, width, batch, dtype, direction, 1.0, scr, (hipStream_t)stream);
-        long_scratch_release(scr, (hipStream_t)stream);
+        long_scratch_release(lease);
         return rc;
     }
     const void* tw = nullptr;

@@ -8,11 +8,15 @@ namespace dfft {
 
 enum { ZY_MAX_PLANES = 4096 };
 
+// why a launch gave up (ZyCtl::error and the host-visible word)
+enum { ZY_ERR_TIMEOUT = 1,   // a consumer unit polled spin_polls times for its plane's producers
+       ZY_ERR_DESYNC = 2 };  // the first ticket of a launch did not fit its ticket_base: counters out of step with the host
+
 // control block in device memory, zeroed once when the plan is created (launches count on from where the last one stopped)
 struct alignas(128) ZyCtl {
     unsigned ticket;               // next work item
     unsigned pad0[31];
-    unsigned error;                // != 0: a consumer unit waited longer than 20 ms for its plane (the launch gave up)
+    unsigned error;                // != 0 (ZY_ERR_*): a launch gave up; sticky -- every later launch on this block returns at once
     unsigned pad1[31];
     unsigned done[ZY_MAX_PLANES];  // per plane: producer units that have published their results
 };
@@ -35,6 +39,8 @@ struct ZyLaunch {
     RotMap      rot;          // rot != 0: rows of the packed layout are rotated by rot * (plane + a0) elements (mask = N2 - 1)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
     int         lazy;         // un-packed launches: the lazy-publish variant of the kernel (the default; DFFT_ZY_LAZY=0: eager)
+    unsigned*   err_host;     // device pointer of a pinned host word: written with ZY_ERR_* when the launch gives up
+    unsigned    spin_polls;   // bound of a consumer's wait, in polls of its plane's counter (1-3 us each)
 };
 
 bool       zy_supported(int dtype, int n1, int n2);

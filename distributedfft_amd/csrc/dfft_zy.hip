@@ -17,8 +17,13 @@
 // Deadlock freedom: tickets are taken in order by RUNNING workgroups only; a producer unit never waits; a consumer unit waits only
 // for producer units with smaller tickets, and a workgroup never holds an unprocessed item -- nor, in the lazy form, an unpublished
 // producer unit -- while it waits (the next item is prefetched only if its dependency is already satisfied).  Every spin is bounded
-// by the wall clock; a time-out sets ctl->error, every workgroup leaves, and the host reports it at the next synchronisation (and
-// goes back to the two-launch path).
+// by a number of POLLS (spin_polls, about 1-3 us each: seconds in all -- not by the wall clock, which keeps running while the
+// process's queues are preempted by another process on the GPU, a profiler or a debugger); a time-out sets ctl->error and the
+// host-visible error word, every workgroup leaves, and every later launch on the same control block refuses to run (the error is
+// sticky, and a launch whose first ticket is implausible for its ticket_base -- counters out of step with the host -- raises it
+// too), so a desynchronised stage can never return garbage silently.  The host sees the pinned word without a copy: it reports
+// the failure at the next execute / synchronisation, re-runs a host-synchronised execute on the two-launch path where the input
+// is still intact, and never uses the stage again (dfft_plan.cpp, zy_check).
 //
 // Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes); single-GPU fused
 // plans (hand-over buffer or bufferDev1 as w) and P > 1 fused plans with even splits (the Y side then reads / writes the packed,
@@ -48,7 +53,7 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
-                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm) {
+                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls) {
     using V = double2;
     constexpr int CB = 8;  // column tiles of one cache line
     constexpr int THREADS = CB * PY::T;
@@ -61,7 +66,6 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     constexpr unsigned UA = DIR > 0 ? UZ : UY, UB = DIR > 0 ? UY : UZ, BB = UA + UB;  // producer / consumer units per plane
     constexpr bool     TWPOW = true;
     constexpr int      ROW_LDS = N2 + N2 / 8;  // padded row (lds_index<1, true>)
-    constexpr unsigned LIMIT = 20u * 1000u * 100u;  // 20 ms of the 100 MHz wall clock
 
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     unsigned* shw = reinterpret_cast<unsigned*>(dfft_smem);  // [0] ticket broadcast, [1] dependency state
@@ -111,21 +115,26 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - ticket_base : 0u;
     };
     // dependency of a consumer unit: every producer unit of its plane has published.  wait = false: one poll only.
+    // give up: sticky error in the control block (seen by every workgroup of this and of later launches) + the host-visible word
+    auto raise = [&](unsigned code) {
+        __hip_atomic_store(&ctl->error, code, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+        __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
     auto ready = [&](const Item& it, bool wait) -> bool {
         if (it.kind != CONS) return true;
         if (tid == 0) {
             unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA ? 1u : 0u;
             if (!ok && wait) {
-                const unsigned long long t0 = wall_clock64();
-                for (;;) {
+                // bounded by polls this wave actually makes, not by elapsed time: a preempted process does not time out
+                for (unsigned polls = 0;; ++polls) {
                     __builtin_amdgcn_s_sleep(1);
                     if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA) {
                         ok = 1u;
                         break;
                     }
                     if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) break;
-                    if (wall_clock64() - t0 > LIMIT) {
-                        __hip_atomic_store(&ctl->error, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+                    if (polls >= spin_polls) {
+                        raise(ZY_ERR_TIMEOUT);
                         break;
                     }
                 }
@@ -254,7 +263,22 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 
     V v[E], vn[E];
     // tickets are taken two items ahead, so that the atomic's round trip overlaps a whole unit of work
-    Item cur = decode(share(take()));
+    // A launch takes total + 2 * grid tickets in all.  A first ticket outside that range means the control block's counter is out
+    // of step with the host's ticket_base (an earlier launch gave up before its workgroups had taken their last tickets): every
+    // item would decode as NONE and the launch would "finish" without computing -- refuse loudly instead.  So does every launch
+    // behind a failed one (sticky error word).
+    unsigned first = take();
+    if (tid == 0) {
+        if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) {
+            first = 0xffffffffu;
+        } else if (first >= total + 2u * gridDim.x) {
+            raise(ZY_ERR_DESYNC);
+            first = 0xffffffffu;
+        }
+    }
+    first = share(first);
+    if (first == 0xffffffffu) return;
+    Item cur = decode(first);
     Item nxt = decode(share(take()));
     if (cur.kind != NONE) {
         if (!ready(cur, true)) return;
@@ -365,7 +389,7 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
                        (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.plane0, (unsigned)L.nplanes,
-                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot);
+                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls);
     return hipGetLastError();
 }
 
@@ -391,7 +415,8 @@ unsigned zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk)
 }
 
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
-    if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0) return hipErrorInvalidValue;
+    if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0 || !L.err_host || L.spin_polls == 0)
+        return hipErrorInvalidValue;
 // DFFT_ZY_LAZY_PACKED=1 (build-time experiment, not yet run): the lazy-publish form for the packed P > 1 launches too (opt-in plans,
 // DFFT_T0_ONE_LAUNCH=all; its results will differ from the two-launch path in the last bit like the un-packed form's)
 #ifndef DFFT_ZY_LAZY_PACKED

@@ -187,8 +187,10 @@ inline fft_mpi_3d_plan_p fft_mpi_plan_dft_c2c_3d(longInt64 n0, longInt64 n1, lon
     DFFT_CHECK(dfft_plan_create(&plan->handle, n0, n1, n2, DFFT_F64, direction, in, out, c, plan->globalDevIdx,
                                 totalDevCount, plan_flags));
     // plan-time placement of the internal hand-over buffer (dfft_plan_tune, a few X-pass kernel launches): done here so that
-    // `sh speedTest.sh 1 X Y Z` times the same configuration as bench.py.  Out-of-place plans only -- the probe launches of a
-    // forward plan leave garbage in `out`, which an in-place caller would read as its input.  DFFT_TUNE=0 switches it off.
+    // `sh speedTest.sh 1 X Y Z` times the same configuration as bench.py.  The probe launches of a forward plan write into `out`;
+    // dfft_plan_tune sets its contents aside and puts them back (like the reference's, this plan creation leaves `out` as it found
+    // it), borrows at most a quarter of the free device memory (DFFT_TUNE_MEM_PCT) and 32 candidates (DFFT_TUNE_TRIES), and is
+    // skipped for in-place plans.  DFFT_TUNE=0 switches it off.
     if (!plan->isInplace) DFFT_CHECK(dfft_plan_tune(plan->handle));
     plan->bufferDev1 = (Complex*)dfft_plan_buffer1(plan->handle);
     plan->bufferDev2 = (Complex*)dfft_plan_result(plan->handle);
