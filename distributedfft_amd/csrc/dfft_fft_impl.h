@@ -170,15 +170,20 @@ constexpr int tw_slots(int R, bool pow2only) { return !pow2only ? R - 1 : (R >= 
 #endif
 template <class P> constexpr bool tw_sharing() { return DFFT_TW_EFFECTIVE || P::N >= 4096; }
 
-// DFFT_TW_STAGE_MAJOR=1 (build-time experiment, not yet measured -- prepared at the end of round 3 without GPU time left): the LDS
-// copy of the twiddle table (TW_LDS kernels: 16 points per thread, 1024 / 2048 points) is laid out [stage][m][r - 1] like the
-// reference's LUT (templateFFT.cpp:5120-5141) instead of as the natural N-entry table read at r * m * N / (Ns R).  In the early
-// stages (small Ns) the lanes of a ds_read_b128 group read a handful of distinct entries a power-of-two number of bytes apart --
-// the same banks, 2-4-way conflicts on R - 1 reads per butterfly (SQ_LDS_BANK_CONFLICT 9-36 % of these kernels' LDS cycles,
-// profiles/r03/experiments/lds_bank_conflicts_long_x_pass.log); stage-major they are consecutive.  Same values, so results must be
-// bit-identical to the default build.  Entries: sum over stages s >= 1 of Ns (R - 1) = N - R_0 <= N: the same LDS area.
+// Stage-major LDS twiddle table (the default since round 4; -DDFFT_TW_STAGE_MAJOR=0 builds the natural-order table for A/B runs): the
+// LDS copy of the twiddle table (TW_LDS kernels: 16 / 24 points per thread -- 768, 1024, 2048 points) is laid out [stage][m][r - 1]
+// like the reference's LUT (templateFFT.cpp:5120-5141) instead of as the natural N-entry table read at r * m * N / (Ns R).  In the
+// early stages (small Ns) the lanes of a ds_read_b128 group read a handful of distinct entries a power-of-two number of bytes apart
+// -- the same banks, 2-4-way conflicts on R - 1 reads per butterfly (SQ_LDS_BANK_CONFLICT 9-36 % of these kernels' LDS cycles,
+// profiles/r03/experiments/lds_bank_conflicts_long_x_pass.log); stage-major they are consecutive, and the per-point index
+// arithmetic shrinks (1024-point X pass 228 -> 220 VGPRs, paired 2048-point tiles 234 -> 212).  Same table values: bit-identical
+// results (sha256 of eight 3D results, profiles/r04/experiments/lib_ab_stage_major_twiddles.log).  Measured, two processes each,
+// interleaved: X pass of 2048 x 2048 x 1024 fp32 per rank at P = 8 (config 5) 1.947 -> 1.813 ms (4.41 -> 4.74 TB/s), 1024^3 fp32
+// 3.17 -> 3.06, 2048 x 1024 x 512 fp64 7.11 -> 6.96, fp32 4.61 -> 4.54, 1024 x 768 x 512 fp64 2.729 -> 2.710, fp32 1.116 -> 1.098; t0 with
+// a 768- / 1024-point Y axis -1 ... -2.5 %; nothing slower.  Entries: sum over stages s >= 1 of Ns (R - 1) = N - R_0 <= N: the
+// same LDS area.
 #ifndef DFFT_TW_STAGE_MAJOR
-#define DFFT_TW_STAGE_MAJOR 0
+#define DFFT_TW_STAGE_MAJOR 1
 #endif
 template <class P, int S, bool TWPOW> struct StageInfo {
     using Prev = StageInfo<P, S - 1, TWPOW>;
@@ -249,7 +254,7 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
     }
 }
 
-// LDS copy of the twiddle table for TW_LDS kernels in stage-major order (DFFT_TW_STAGE_MAJOR builds only)
+// LDS copy of the twiddle table for TW_LDS kernels in stage-major order
 template <class W, class P, int S, int DIR> __device__ __forceinline__ void fill_stage_major(W* dst, const W* __restrict__ tw, int tid, int threads) {
     if constexpr (S < P::S) {
         using SI = StageInfo<P, S, false>;

@@ -507,12 +507,12 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     // the control block's counters run on from launch to launch (no reset between transforms): the ticket counter by what every
     // launch consumes, the per-plane counters by the producers of one plane per execute
     unsigned producers = 0;
-    (void)zy_units_per_plane(L.n1, L.n2, L.dir, &producers);
+    (void)zy_units_per_plane(L.n1, L.n2, L.dir, L.packed, &producers);
     if (x0 == 0) p->zy_cur = p->zy_execs++;
     L.ticket_base = p->zy_ticket;
     L.done_base = p->zy_cur * producers;
-    if (p->zy_fault > 0 && ++p->zy_launches == (unsigned)p->zy_fault) ++L.done_base;  // test hook: this launch's consumers can never start
-    p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.nplanes, L.chunk);
+    if (p->zy_fault > 0 && ++p->zy_launches == (unsigned)p->zy_fault) L.fault = 1;  // test hook: this launch's consumers can never start
+    p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.packed, L.nplanes, L.chunk);
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
 }
 
@@ -1186,17 +1186,19 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2);
         const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % (n1 / 8) == 0;  // even splits; a
                                    // destination block is a whole number of the column unit's 8-point-per-thread strides
-        // P > 1 plans only on request (DFFT_T0_ONE_LAUNCH=all): measured per rank at 512^3 fp64 the packed form gains nothing over two
-        // launches per chunk (P = 4: 0.339 vs 0.338 ms; profiles/r03/experiments/local_by_P_one_launch.log) -- the Y units then
-        // stream their results to HBM instead of working in the cache, and a part of the overlapped pipeline is a single phase anyway
-        const bool      multi_on = oe && !strcmp(oe, "all");
-        // By itself only for 512 x 512-point planes (64 KiB units): with a 256-point axis in the plane the units are 32 KiB, a
-        // workgroup's per-unit overhead (ticket, dependency poll, quiet point) weighs twice as much and two launches per chunk win
-        // -- 256^3 fp64: t0 0.170 vs 0.216 ms (BASELINE config 2: 0.244 vs 0.298 ms per transform), 512 x 256 x 256: 0.357 vs
-        // 0.422, 256 x 256 x 512: 0.348 vs 0.424, against 256 x 512 x 512: 0.694 vs 0.593 (profiles/r03/experiments/
-        // variant_ab_256.log; two or three of the 256-thread workgroups per CU do not change that).  DFFT_T0_ONE_LAUNCH=1 / all force it.
-        const bool      pays = (n1 == 512 && n2 == 512) || (oe && *oe && *oe != '0');
-        if (!(oe && *oe == '0') && pays && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
+        // Where the stage is used by itself (DFFT_T0_ONE_LAUNCH=0: never; =1: wherever the kernel exists on single-GPU plans; =all:
+        // P > 1 plans too).  Round 3 used it for 512 x 512-point planes on a single GPU only; since round 4
+        //  * un-packed launches with a 256-point Y axis take column tiles of two cache lines (ZyTile, dfft_zy.hip: 512-thread
+        //    workgroups and 64 KiB units again), and the stage wins on every plane shape it is built for -- t0 / back-to-back ms per
+        //    transform, two launches per chunk -> one launch: 256^3 (BASELINE config 2) 0.169 / 0.2445 -> 0.154 / 0.2350, 512 x 256 x 256
+        //    0.357 / 0.510 -> 0.305 / 0.463, 256 x 256 x 512 0.349 / 0.509 -> 0.307 / 0.469, 256 x 512 x 256 0.355 / 0.528 -> 0.309 / 0.470
+        //    (profiles/r04/experiments/variant_ab_256_wide_tiles.log; with one-line tiles it lost: 0.170 vs 0.216 at 256^3);
+        //  * the packed launches of P > 1 plans run the lazy-publish form too (it measured equal to two launches while it published
+        //    eagerly): per rank at 512^3 fp64, exchange switched off, t0 / back-to-back P = 2 0.690 / 1.052 -> 0.630 / 0.94, P = 4
+        //    0.343 / 0.512 -> 0.32 / 0.492, P = 8 0.174 / 0.255 -> 0.157 / 0.248 (experiments/lib_ab_lazy_packed.log) -- used by itself
+        //    for 512 x 512-point planes (packed tiles stay one line wide, so planes with a 256-point axis keep two launches).
+        const bool      multi_on = (n1 == 512 && n2 == 512) || (oe && !strcmp(oe, "all"));
+        if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
             // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test
@@ -1375,7 +1377,9 @@ int dfft_plan_tune(dfft_plan_t plan) {
     // only fused single-GPU plans with a hand-over buffer have anything to place
     if (plan->exch || !plan->wbuf || (plan->flags & (DFFT_PLAN_NATURAL | DFFT_PLAN_UNFUSED))) return DFFT_OK;
     dfft_plan_s* p = plan;
-    DFFT_HIP_TRY(hipStreamSynchronize(p->stream));
+    // plan-time call: wait for the whole device, not only for the plan's stream -- the caller may have filled `out` on a stream of
+    // its own (the contents are set aside below and put back at the end; seen as a lost update in the GPU suite of round 4)
+    DFFT_HIP_TRY(hipDeviceSynchronize());
     const size_t wbytes = (size_t)p->xs * p->wl.plane * elem_bytes(p->dtype);
     // Candidates: the current buffer, then fresh allocations of the same size, ALL kept until the end.  The driver hands out
     // device memory block by block (runs of 2 ... 36 consecutive 2 GiB allocations behave alike, then the behaviour flips:
@@ -1496,7 +1500,7 @@ int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     snprintf(buf, (size_t)len,
              "pipeline=%s yz_stage=%s%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d x_variant=%s",
              (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
-             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_lazy && !p->exch) ? "-lazy" : "", nch, cp,
+             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_lazy) ? "-lazy" : "", nch, cp,
              (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0,
              (p->x_hints & FFT_HINT_HALF_PREFETCH) ? "half-prefetch" : ((p->x_hints & FFT_HINT_EARLY_WAIT) ? "early-wait" : "default"));
     return DFFT_OK;

@@ -38,15 +38,16 @@ struct ZyLaunch {
     long long   pk_plane;     // distance between consecutive X planes inside a block of the packed layout
     RotMap      rot;          // rot != 0: rows of the packed layout are rotated by rot * (plane + a0) elements (mask = N2 - 1)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
-    int         lazy;         // un-packed launches: the lazy-publish variant of the kernel (the default; DFFT_ZY_LAZY=0: eager)
+    int         lazy;         // the lazy-publish variant of the kernel (the default; DFFT_ZY_LAZY=0: eager)
+    int         fault;        // test hook: the consumers of this launch wait for one producer more than a plane has
     unsigned*   err_host;     // device pointer of a pinned host word: written with ZY_ERR_* when the launch gives up
     unsigned    spin_polls;   // bound of a consumer's wait, in polls of its plane's counter (1-3 us each)
 };
 
 bool       zy_supported(int dtype, int n1, int n2);
 long long  zy_grid();
-unsigned   zy_units_per_plane(int n1, int n2, int dir, unsigned* producers);
-unsigned   zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk);
+unsigned   zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers);
+unsigned   zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk);
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream);
 
 }  // namespace dfft

@@ -44,19 +44,28 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 // DIR = -1: producers = Y columns (w in place), consumers = Z rows (w -> dst)
 // PACK: the column side that is not w is the packed exchange layout of a P > 1 plan (forward: Y columns w -> packed send buffer,
 // backward: packed receive buffer -> w) described by the launcher's axis map `pk`, with the rows rotated per plane (RotMap mode 1)
-// LAZY (un-packed launches; the plan's default, DFFT_ZY_LAZY=0 selects the eager form): gfx9 counts loads and stores in one vmcnt, so "wait for the prefetched unit" after a
+// LAZY (the plan's default for packed and un-packed launches, DFFT_ZY_LAZY=0 selects the eager form): gfx9 counts loads and stores in one vmcnt, so "wait for the prefetched unit" after a
 // unit's stores have been issued means "drain those stores" -- and a producer unit drains them again before it publishes.  The lazy
 // form waits for everything that is in flight (the previous unit's stores, the next unit's loads) after a unit's ARITHMETIC, when
 // it has had a whole unit's exchanges to complete, publishes the PREVIOUS producer unit there, and only then issues this unit's
 // stores, which drain underneath the next unit.  A workgroup never enters a blocking wait with an unpublished unit (flush first).
+// Column tiles: one cache line (8 columns) for 512-point Y axes -- 512 threads, 64 KiB units.  A 256-point Y axis would make that a
+// 256-thread workgroup with 32 KiB units, whose per-unit overhead (ticket, dependency poll, quiet point) weighs twice as much: its
+// un-packed launches take tiles of TWO lines (16 columns), which restores the 512 threads and the 64 KiB.  Packed launches keep one
+// line (a rotated tile position is a multiple of one line, so a wider tile could straddle the end of a row).
+template <class PY, bool PACK> struct ZyTile {
+    static constexpr int CB = (!PACK && PY::T < 64) ? 8 * (64 / PY::T) : 8;
+    static constexpr int THREADS = CB * PY::T;
+};
+
 template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(8 * PY::T, 8 * PY::T), amdgpu_waves_per_eu(1)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(ZyTile<PY, PACK>::THREADS, ZyTile<PY, PACK>::THREADS), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
-                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls) {
+                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls, unsigned need) {
     using V = double2;
-    constexpr int CB = 8;  // column tiles of one cache line
-    constexpr int THREADS = CB * PY::T;
+    constexpr int CB = ZyTile<PY, PACK>::CB;  // columns per tile: one cache line, or two for 256-point Y axes (ZyTile)
+    constexpr int THREADS = ZyTile<PY, PACK>::THREADS;
     constexpr int N2 = PZ::N, N1 = PY::N, E = PZ::E, TZ = PZ::T, TY = PY::T;
     static_assert(PZ::E == PY::E, "one register set serves both item kinds");
     static_assert(TZ <= 64 && 64 % TZ == 0 && THREADS % TZ == 0, "rows: one FFT inside one wavefront");
@@ -114,7 +123,9 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         // wrapping 32-bit arithmetic, so no memset launch sits between two transforms)
         return tid == 0 ? __hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - ticket_base : 0u;
     };
-    // dependency of a consumer unit: every producer unit of its plane has published.  wait = false: one poll only.
+    // dependency of a consumer unit: every producer unit of its plane has published -- `need` of them (= UA; the host's fault-injection
+    // hook passes UA + 1, which no plane ever reaches: tests/test_gpu_parity.py::test_one_launch_t0_failure_is_loud_and_recovered).
+    // wait = false: one poll only.
     // give up: sticky error in the control block (seen by every workgroup of this and of later launches) + the host-visible word
     auto raise = [&](unsigned code) {
         __hip_atomic_store(&ctl->error, code, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
@@ -123,12 +134,12 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     auto ready = [&](const Item& it, bool wait) -> bool {
         if (it.kind != CONS) return true;
         if (tid == 0) {
-            unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA ? 1u : 0u;
+            unsigned ok = __hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= need ? 1u : 0u;
             if (!ok && wait) {
                 // bounded by polls this wave actually makes, not by elapsed time: a preempted process does not time out
                 for (unsigned polls = 0;; ++polls) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= UA) {
+                    if (__hip_atomic_load(&ctl->done[it.plane], __ATOMIC_RELAXED, DFFT_ZY_AGENT) - done_base >= need) {
                         ok = 1u;
                         break;
                     }
@@ -366,8 +377,9 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 }
 
 template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
-    constexpr int    THREADS = 8 * PY::T, GR = THREADS / PZ::T;
-    constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * 8 * sizeof(double2);
+    constexpr int    CB = ZyTile<PY, PACK>::CB, THREADS = ZyTile<PY, PACK>::THREADS, GR = THREADS / PZ::T;
+    constexpr unsigned UA = DIR > 0 ? (unsigned)(PY::N / GR) : (unsigned)(PZ::N / CB);  // producer units per plane, as in the kernel
+    constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * CB * sizeof(double2);
     constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
     auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY>;
     static std::atomic<bool> attr_set[64];
@@ -389,7 +401,7 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
                        (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.plane0, (unsigned)L.nplanes,
-                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls);
+                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls, UA + (L.fault ? 1u : 0u));
     return hipGetLastError();
 }
 
@@ -403,35 +415,25 @@ bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256
 // workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
 // advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.
 long long zy_grid() { return device_info().cus; }
-unsigned  zy_units_per_plane(int n1, int n2, int dir, unsigned* producers) {
-    const int      ty = n1 / 8, tz = n2 / 8, threads = 8 * ty, gr = threads / tz;
-    const unsigned uz = (unsigned)(n1 / gr), uy = (unsigned)(n2 / 8);
+unsigned  zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers) {
+    const int      ty = n1 / 8, tz = n2 / 8, cb = (!packed && ty < 64) ? 8 * (64 / ty) : 8;  // ZyTile
+    const int      threads = cb * ty, gr = threads / tz;
+    const unsigned uz = (unsigned)(n1 / gr), uy = (unsigned)(n2 / cb);
     if (producers) *producers = dir > 0 ? uz : uy;
     return uz + uy;
 }
-unsigned zy_tickets(int n1, int n2, int dir, long long nplanes, long long chunk) {
+unsigned zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk) {
     const unsigned nchunks = (unsigned)((nplanes + chunk - 1) / chunk);
-    return nchunks * (unsigned)chunk * zy_units_per_plane(n1, n2, dir, nullptr) + 2u * (unsigned)zy_grid();
+    return nchunks * (unsigned)chunk * zy_units_per_plane(n1, n2, dir, packed, nullptr) + 2u * (unsigned)zy_grid();
 }
 
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0 || !L.err_host || L.spin_polls == 0)
         return hipErrorInvalidValue;
-// DFFT_ZY_LAZY_PACKED=1 (build-time experiment, not yet run): the lazy-publish form for the packed P > 1 launches too (opt-in plans,
-// DFFT_T0_ONE_LAUNCH=all; its results will differ from the two-launch path in the last bit like the un-packed form's)
-#ifndef DFFT_ZY_LAZY_PACKED
-#define DFFT_ZY_LAZY_PACKED 0
-#endif
-#if DFFT_ZY_LAZY_PACKED
-#define DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_) \
-    if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream);
-#else
-#define DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_)
-#endif
 #define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
-        DFFT_ZY_LAZY_PACKED_CASE(PZ_, PY_)                                                                                      \
-        if (L.lazy && !L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
+        if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream); \
+        if (L.lazy) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
         if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \
         return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false>(L, stream) : launch_zy_t<PZ_, PY_, -1, false>(L, stream);            \
     }

@@ -26,9 +26,14 @@ def _free_port():
     return p
 
 
-def _launch(world, argv, extra_env=None, timeout=600, expect_rc=0):
+def _launch(world, argv, extra_env=None, timeout=300, expect_rc=0):
+    """One process per rank.  A rank that fails (or a hang) is a finding, not just a time-out: as soon as one rank has exited with an
+    unexpected code the others get a few seconds to notice and are then killed -- peers of a dead rank wait in the next rendezvous
+    for ever otherwise -- and the assertion shows what every rank had printed."""
+    import tempfile
+    import time
     port = _free_port()
-    procs = []
+    procs, files = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), DFFT_ROOT=str(ROOT), HSA_ENABLE_IPC_MODE_LEGACY="0",
@@ -36,17 +41,36 @@ def _launch(world, argv, extra_env=None, timeout=600, expect_rc=0):
         env.pop("DFFT_MASTER_PORT", None)
         if extra_env:
             env.update(extra_env)
-        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(ROOT)))
-    outs = []
-    for p in procs:
-        try:
-            outs.append(p.communicate(timeout=timeout))
-        except subprocess.TimeoutExpired:
+        fo, fe = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")  # files, not pipes: nobody blocks on a full pipe
+        files.append((fo, fe))
+        procs.append(subprocess.Popen(argv, env=env, stdout=fo, stderr=fe, text=True, cwd=str(ROOT)))
+    t_end = time.monotonic() + timeout
+    failed_at = None
+    why = ""
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        if failed_at is None and any(p.poll() is not None and p.returncode != expect_rc for p in procs):
+            failed_at = now
+        if now > t_end or (failed_at is not None and now > failed_at + 10.0):
+            why = (f"{world} ranks did not finish within {timeout} s" if now > t_end
+                   else "a rank exited with an unexpected code; its peers were killed 10 s later")
             for q in procs:
-                q.kill()
-            raise
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == expect_rc, (o + e)[-3000:]
+                if q.poll() is None:
+                    q.kill()
+            for q in procs:
+                q.wait()
+            break
+        time.sleep(0.1)
+    outs = []
+    for fo, fe in files:
+        fo.seek(0)
+        fe.seek(0)
+        outs.append((fo.read(), fe.read()))
+        fo.close()
+        fe.close()
+    if why or any(p.returncode != expect_rc for p in procs):
+        tails = "\n".join(f"--- rank {r} rc={p.returncode}\n{(o + e)[-2500:]}" for r, (p, (o, e)) in enumerate(zip(procs, outs)))
+        raise AssertionError((why or f"unexpected exit code (expected {expect_rc})") + "\n" + tails)
     return outs
 
 

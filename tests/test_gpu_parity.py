@@ -73,8 +73,9 @@ def test_fft1d_cols_vs_oracle(gpu, n, width, prec):
     assert _rel_err(back, np.fft.ifft(x, axis=1) * n) < TOL[prec]
 
 
-def _run_plans(gpu, N, P, prec, x, direction, flags=0, inputs=None, exec_flags=0):
-    """Create P plans (virtual devices on one GPU, LOCAL communicator), execute them from P threads, return outputs."""
+def _run_plans(gpu, N, P, prec, x, direction, flags=0, inputs=None, exec_flags=0, describes=None):
+    """Create P plans (virtual devices on one GPU, LOCAL communicator), execute them from P threads, return outputs
+    (describes: a list that receives dfft_plan_describe of every plan)."""
     import torch
     from distributedfft_amd import api
     n0, n1, n2 = N
@@ -89,6 +90,8 @@ def _run_plans(gpu, N, P, prec, x, direction, flags=0, inputs=None, exec_flags=0
         a[:src.numel()] = src
         torch.cuda.synchronize()
         plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, direction, flags))
+        if describes is not None:
+            describes.append(plans[-1].describe())
         ins.append(a)
         outs.append(b)
     errs = []
@@ -408,7 +411,9 @@ def test_one_launch_t0_failure_is_loud_and_recovered(gpu, direction, monkeypatch
 def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatch):
     """P > 1: the one-launch YZ stage stores its column results straight into the packed (and, with DFFT_ROT=1, row-rotated) send
     layout, the inverse reads the packed receive layout -- whole slabs in the serial pipeline, X-plane parts in the overlapped
-    one.  Bit-identical to two launches per chunk in both directions; against the oracle once."""
+    one.  The eager-publish kernel is bit-identical to two launches per chunk in both directions; the lazy-publish one (the
+    default since round 4) agrees to the last bit or two, is the same in the serial and the overlapped pipeline, and both are
+    checked against the oracle."""
     from distributedfft_amd import api
     monkeypatch.setenv("DFFT_ROT", rot)
     monkeypatch.setenv("DFFT_CHUNK_PLANES", "3")   # several phases per slab / part
@@ -416,21 +421,41 @@ def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatc
     x = so.random_input(N, seed=77 + P)
     ref = so.fftn_reference(x, P)
     inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "all" if mode == "1" else "0")   # P > 1 plans use the stage only on request
-        for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP):
-            fwd, _ = _run_plans(gpu, N, P, "f64", x, +1, flags, inputs)
-            bwd, _ = _run_plans(gpu, N, P, "f64", None, -1, flags, [r for r in ref])
+    res, one = {}, {}
+    all_flags = (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP)
+    for mode in ("0", "eager", "lazy"):
+        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "0" if mode == "0" else "all")   # planes with a 256-point axis use the stage only on request
+        monkeypatch.setenv("DFFT_ZY_LAZY", "0" if mode == "eager" else "1")
+        for flags in all_flags:
+            desc = []
+            fwd, _ = _run_plans(gpu, N, P, "f64", x, +1, flags, inputs, describes=desc)
+            bwd, _ = _run_plans(gpu, N, P, "f64", None, -1, flags, [r for r in ref], describes=desc)
             res[(mode, flags)] = (fwd, bwd)
+            # (an overlapped plan whose Y sub-blocks are narrower than the column unit's stride keeps two launches per chunk)
+            one[(mode, flags)] = all("yz_stage=one-launch" in t for t in desc)
+            if mode == "0":
+                assert not any("yz_stage=one-launch" in t for t in desc)
+            elif flags == all_flags[0]:   # the serial pipeline of every shape in the list runs the stage: the test is not vacuous
+                assert one[(mode, flags)] and all(("yz_stage=one-launch-lazy" in t) == (mode == "lazy") for t in desc), desc[0]
     scale = max(np.abs(r).max() for r in ref)
-    for flags in (api.PLAN_INPUT_FROM_IN, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP):
+    in_scale = float(np.abs(x).max()) * n0 * n1 * n2
+    for flags in all_flags:
+        # what the lazy plans of this pipeline must reproduce bit for bit: the serial lazy plans, or the two-launch path where the
+        # overlapped plan does not use the stage
+        same = ("lazy", all_flags[0]) if one[("lazy", flags)] else ("0", flags)
         for d in range(P):
             cnt = ref[d].size
-            assert np.array_equal(res[("1", flags)][0][d][:cnt], res[("0", flags)][0][d][:cnt]), (N, P, flags, d)
-            assert np.abs(res[("1", flags)][0][d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < 1e-11
+            two, eager, lazy = (res[(m, flags)][0][d][:cnt] for m in ("0", "eager", "lazy"))
+            assert np.array_equal(eager, two), (N, P, flags, d)
+            assert np.abs(lazy - two).max() / scale < 1e-14, (N, P, flags, d)
+            assert np.array_equal(lazy, res[same][0][d][:cnt]), (N, P, flags, d, same)
+            for got in (eager, lazy):
+                assert np.abs(got.reshape(ref[d].shape) - ref[d]).max() / scale < 1e-11
             cnt = inputs[d].size
-            assert np.array_equal(res[("1", flags)][1][d][:cnt], res[("0", flags)][1][d][:cnt]), (N, P, flags, d, "backward")
+            two, eager, lazy = (res[(m, flags)][1][d][:cnt] for m in ("0", "eager", "lazy"))
+            assert np.array_equal(eager, two), (N, P, flags, d, "backward")
+            assert np.abs(lazy - two).max() / in_scale < 1e-14, (N, P, flags, d, "backward")
+            assert np.array_equal(lazy, res[same][1][d][:cnt]), (N, P, flags, d, "backward", same)
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])

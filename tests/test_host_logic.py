@@ -308,7 +308,7 @@ def test_headline_kernels_do_not_spill():
     # the one-launch YZ stage (csrc/dfft_zy.hip; the headline's t0): every instantiation, and the lazy-publish kernels with room to
     # spare (they keep the products of their twiddle powers out of the unit loop's invariants: 192-200 registers)
     rows = kr.zy_table()
-    assert len(rows) == 24, len(rows)
+    assert len(rows) == 32, len(rows)   # 4 plane shapes x 2 directions x packed / un-packed x eager / lazy
     for tag, vgpr, scratch, _ in rows:
         assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
         assert vgpr <= (224 if tag.endswith("lazy") else 256), f"{tag}: {vgpr} registers"
