@@ -641,7 +641,19 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     };
     auto load_tile = [&](unsigned t, V* dst) { load_part(t, dst, std::integral_constant<int, 0>{}, std::integral_constant<int, E>{}); };
     // only where the second register set is cheap: <= 32 VGPRs and blocks that do not need the 128-VGPR budget
-    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH) && KG::THREADS <= 512;
+    // (round 4) ... and where the second set is free: a workgroup of at most 256 threads is one wave per SIMD, which may use all 512
+    // registers of its lanes (the compiler parks what does not fit the 256 architectural ones in AGPRs; loads can target them), and
+    // a tile beyond 80 KiB means one workgroup per CU anyway -- the 768-point column kernels (24 points per thread, 96 KiB tiles:
+    // config 4's Y axis) have nothing in flight underneath their exchanges.  -DDFFT_WIDE_PREFETCH=1 builds it, =2 adds the early wait
+    // (the prefetched tile is waited for before this tile's stores are issued, so that they drain underneath the next tile: what the
+    // lazy one-launch YZ stage does).  Measured and NOT adopted (round 4, 362-392 registers, no scratch, bit-identical):
+    // profiles/r04/experiments/lib_ab_wide_prefetch.log.
+#ifndef DFFT_WIDE_PREFETCH
+#define DFFT_WIDE_PREFETCH 0
+#endif
+    constexpr bool WIDE = DFFT_WIDE_PREFETCH && KG::THREADS <= 256 && KG::LDS_BYTES > 80 * 1024 && !GENERAL;
+    constexpr bool EARLY = Tune::EARLY_WAIT || (WIDE && DFFT_WIDE_PREFETCH >= 2);
+    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH || WIDE) && KG::THREADS <= 512;
     // 16 points per thread (1024- and 2048-point columns) without Tune::FULL_PREFETCH: a whole second register set does not fit next
     // to per-point offsets (64 VGPRs: 4.6 -> 3.7 TB/s, round 1), but the kernels leave room for HALF of one -- the first 8 points of
     // the next tile are fetched underneath the current tile's exchanges and stores, the other 8 at the top of the next iteration.
@@ -704,7 +716,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 #pragma unroll
                     for (int l = 0; l < LANES; ++l) img[(c * LANES + l) * ROW + j + T * k] = VT::lane(cscale(v[k], sc), l);
                 group_sync<KG::WAVE_LOCAL>();
-                if constexpr (Tune::EARLY_WAIT && PF > 0) {
+                if constexpr (EARLY && PF > 0) {
 #pragma unroll
                     for (int k = 0; k < PF; ++k) pin_loaded(vnext[k]);
                 }
@@ -741,7 +753,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
                 }
             }
         } else if (valid) {
-            if constexpr (Tune::EARLY_WAIT && PF > 0) {
+            if constexpr (EARLY && PF > 0) {
 #pragma unroll
                 for (int k = 0; k < PF; ++k) pin_loaded(vnext[k]);
             }
@@ -837,6 +849,110 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
     // rotated rows of the receive buffer (RotMap mode 2): the pair of tiles of plane j + T k starts rot * plane further on in its row
     const int rot_j = ROT ? (rm.rot * j) & rm.mask : 0, rot_t = ROT ? (rm.rot * T) & rm.mask : 0;
+    // -DDFFT_DUAL_PIPELINE=1 (build-time experiment of round 4, measured and NOT adopted): a software pipeline over tile pairs.
+    // The two register sets hold the whole pair (2 E points of 16 bytes per thread: nothing is left for a third set), so the
+    // shipped form loads a pair, transforms and stores its halves, and only then loads the next pair -- with nothing in flight
+    // underneath the arithmetic.  The pipelined form refills the registers of a half as soon as its stores have been issued (below).
+    // Bit-identical, no scratch in fp64 (242 VGPRs), 8-16 B on fp32 pairs -- and slower in 6 of 8 plans, two processes each,
+    // interleaved with the shipped build (profiles/r04/experiments/lib_ab_pipelined_2048.log): X pass of 2048 x 1024 x 512 fp64 7.55 ->
+    // 8.11 ms, config 5's per rank (fp32, rotated rows, P = 8) 1.86 -> 2.07, P = 4 3.71 -> 4.1; only the un-rotated fp32 form gained
+    // (4.58 -> 4.16).  Every iteration still ends in a full drain (the second refill group is needed at the top of the next one),
+    // the refills are half as deep as the whole-pair burst, and the body is written out twice (19 -> 38 KiB of code).
+#ifndef DFFT_DUAL_PIPELINE
+#define DFFT_DUAL_PIPELINE 0
+#endif
+#if DFFT_DUAL_PIPELINE
+    auto in_ptr = [&](unsigned t) -> const GV* {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        return in + (long long)a * itile.a_stride + (long long)b * (2 * CB) * itile.b_stride + ithr;
+    };
+    auto out_ptr = [&](unsigned t, int h) -> GV* {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        return out + (long long)a * otile.a_stride + (long long)b * (2 * CB) * otile.b_stride + (long long)h * CB * LANES * omap.cstride;  // omap.cstride: distance between SCALAR columns
+    };
+    // One half of a tile pair: the 4-column transform through the LDS tile, the staged image, the transposing store.
+    auto process_half = [&](V* v, GV* oh) {
+        run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1>(v, ldstw, lds, j, c);
+        W* img = reinterpret_cast<W*>(lds);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) {
+                const int col = c * LANES + l;
+                img[img_at(col, j + T * k)] = VT::lane(cscale(v[k], sc), l);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int lin = tid + GT * k;
+            const int col = lin / ON;
+            const GV  r = *reinterpret_cast<const GV*>(img + img_at(col, (lin % ON) * LANES));
+            gstore<NT>(oh + (long long)col * omap.cstride + (lin % ON), r);
+        }
+        __syncthreads();  // the image is read before the next half's exchange overwrites the tile
+    };
+    // point k of both halves of tile pair t (the two loads of a lane group are the two halves of the same 128-byte lines)
+    auto load_point = [&](unsigned t, int k, V& a0, V& a1) {
+        const GV* ip = in_ptr(t);
+        long long off = iuni[k];
+        if constexpr (ROT) {
+            const int cb0 = (int)((t % tiles_per_a) * (2 * CB));
+            off += (long long)(((cb0 + rot_j + k * rot_t) & rm.mask) - cb0);
+        }
+        a0 = VT::from_g(gload<NT>(ip + off));
+        a1 = VT::from_g(gload<NT>(ip + off + (long long)CB * imap.cstride));
+    };
+    // The registers of a half are refilled as soon as that half's stores have been issued: after half 0
+    // the points k < E/2 of BOTH halves of the next pair (a lane group still fetches whole 128-byte lines -- loading one half's
+    // columns first would fetch every line twice, profiles/r02/experiments/dual_tiles.log), after half 1 the points k >= E/2.
+    // The loads of the first group complete underneath the second half's exchanges, those of the second group underneath
+    // the drain of its stores.  Loaded registers must not be moved (a move waits for its load), so the assignment of points to
+    // registers alternates between two layouts and the loop body is written out for both:
+    //   layout 0: A = half 0 (all k), B = half 1;   layout 1: half 0 = {A[k], B[k]}, half 1 = {A[E/2 + k], B[E/2 + k]}, k < E/2
+    constexpr int EH = E / 2;
+    static_assert(E % 2 == 0, "dual tiles: even number of points per thread");
+    V A[E], B[E];
+    unsigned t = blockIdx.x;
+    if (t < ntiles) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) load_point(t, k, A[k], B[k]);
+    }
+    // (the prefetch is unconditional: past the workgroup's last pair it re-reads that pair -- two branches less in a loop body
+    // that sits at the register limit)
+    const unsigned step = gridDim.x;
+    while (t < ntiles) {
+        {  // layout 0 -> 1
+            const unsigned tn = t + step, tl = tn < ntiles ? tn : t;
+            process_half(A, out_ptr(t, 0));
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_point(tl, k, A[k], A[EH + k]);
+            process_half(B, out_ptr(t, 1));
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_point(tl, EH + k, B[k], B[EH + k]);
+            t = tn;
+            if (t >= ntiles) break;
+        }
+        {  // layout 1 -> 0
+            const unsigned tn = t + step, tl = tn < ntiles ? tn : t;
+            V              w0[E], w1[E];
+#pragma unroll
+            for (int k = 0; k < EH; ++k) {
+                w0[k] = A[k];
+                w0[EH + k] = B[k];
+                w1[k] = A[EH + k];
+                w1[EH + k] = B[EH + k];
+            }
+            process_half(w0, out_ptr(t, 0));
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_point(tl, k, A[k], B[k]);
+            process_half(w1, out_ptr(t, 1));
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_point(tl, EH + k, A[EH + k], B[EH + k]);
+            t = tn;
+        }
+    }
+#else
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         const GV*      ip = in + (long long)a * itile.a_stride + (long long)b * (2 * CB) * itile.b_stride + ithr;
@@ -877,6 +993,7 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
             __syncthreads();  // the image is read before the next half's exchange overwrites the tile
         }
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -948,6 +1065,98 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
     const long long othr = (long long)(2 * j) * omap.stride + (long long)c * omap.cstride;
     const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+    // -DDFFT_DIF2_PIPELINE=1 (build-time experiment of round 4, measured and NOT adopted; see fft_dual_tiles_kernel): t0 of
+    // 512 x 2048 x 512 fp64 6.19 -> 5.97 ms, but fp32 3.16 -> 3.66, config 5's per-rank t0 3.27 -> 3.37 (12 B of scratch on fp32 pairs).
+#ifndef DFFT_DIF2_PIPELINE
+#define DFFT_DIF2_PIPELINE 0
+#endif
+#if DFFT_DIF2_PIPELINE
+    auto in_ptr = [&](unsigned t) -> const GV* {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
+        int cbi = (int)(b * CB);
+        if constexpr (ROT == 1) {
+            if (rm.in_mode == 1) cbi = (cbi + rm.rot * (int)(a + (unsigned)rm.a0)) & rm.mask;
+        }
+        return in + (long long)a * itile.a_stride + (long long)cbi * itile.b_stride + ithr;
+    };
+    auto out_ptr = [&](unsigned t) -> GV* {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        int cbo = (int)(b * CB);
+        if constexpr (ROT == 1) {
+            if (rm.out_mode == 1) cbo = (cbo + rm.rot * (int)(a + (unsigned)rm.a0)) & rm.mask;
+        }
+        return out + (long long)a * otile.a_stride + (long long)cbo * otile.b_stride + othr;
+    };
+    // the two inputs n = j + T k and n + NH of first-stage butterfly k
+    auto load_pair = [&](unsigned t, int k, V& x0, V& x1) {
+        const GV* ip = in_ptr(t);
+        x0 = VT::from_g(gload<NTL>(ip + in_off(k)));
+        x1 = VT::from_g(gload<NTL>(ip + in_off(k + E)));
+    };
+    auto split = [&](V& x0, V& x1, int k) {  // (x[n], x[n + NH]) -> (a[n], b[n])
+        const V sum = cadd(x0, x1);
+        const V dif = csub(x0, x1);
+        x0 = sum;
+        x1 = cmul(dif, ldstw[j + T * k]);  // W_N^{j + T k}
+    };
+    auto process_half = [&](V* v, unsigned t, int h) {
+        run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, 2>(v, ldstw, lds, j, c);
+        GV* op = out_ptr(t);
+#pragma unroll
+        for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
+    };
+    // Software pipeline over tiles, as in fft_dual_tiles_kernel: the registers of a half transform are refilled as soon as
+    // its stores have been issued -- after the even half the input pairs k < E/2 of the next tile, after the odd half the pairs
+    // k >= E/2 -- so that half of the next tile's loads complete underneath the odd half's exchanges.  Loaded registers are not
+    // moved; the register layout alternates between
+    //   layout 0: pair k = (A[k], B[k]);   layout 1: pair k = (A[k], A[E/2 + k]) for k < E/2, (B[k - E/2], B[k]) for k >= E/2
+    // and the first-stage butterfly leaves a[k] in the pair's first register, b[k] in its second.
+    constexpr int EH = E / 2;
+    static_assert(E % 2 == 0, "DIF-split tiles: even number of points per thread");
+    V A[E], B[E];
+    unsigned t = blockIdx.x;
+    if (t < ntiles) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) load_pair(t, k, A[k], B[k]);
+    }
+    const unsigned step = gridDim.x;
+    while (t < ntiles) {
+        {  // layout 0 -> 1
+            const unsigned tn = t + step, tl = tn < ntiles ? tn : t;  // (past the last tile: re-read it, see fft_dual_tiles_kernel)
+#pragma unroll
+            for (int k = 0; k < E; ++k) split(A[k], B[k], k);
+            process_half(A, t, 0);
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_pair(tl, k, A[k], A[EH + k]);
+            process_half(B, t, 1);
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_pair(tl, EH + k, B[k], B[EH + k]);
+            t = tn;
+            if (t >= ntiles) break;
+        }
+        {  // layout 1 -> 0
+            const unsigned tn = t + step, tl = tn < ntiles ? tn : t;
+            V              w0[E], w1[E];
+#pragma unroll
+            for (int k = 0; k < EH; ++k) {
+                split(A[k], A[EH + k], k);
+                split(B[k], B[EH + k], EH + k);
+                w0[k] = A[k];
+                w0[EH + k] = B[k];
+                w1[k] = A[EH + k];
+                w1[EH + k] = B[EH + k];
+            }
+            process_half(w0, t, 0);
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_pair(tl, k, A[k], B[k]);
+            process_half(w1, t, 1);
+#pragma unroll
+            for (int k = 0; k < EH; ++k) load_pair(tl, EH + k, A[EH + k], B[EH + k]);
+            t = tn;
+        }
+    }
+#else
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
@@ -980,6 +1189,7 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
             for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
         }
     }
+#endif
 }
 
 struct DeviceInfo {

@@ -167,7 +167,7 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
         L.tiles_per_a = (int)rows_per_plane;
         L.a_first = first_row / rows_per_plane;
     }
-    static const int zgrid = env_grid("DFFT_Z_GRID");
+    const int zgrid = env_grid("DFFT_Z_GRID");  // (read per launch: a tuning knob and the tests' way to give a workgroup many tiles)
     L.grid_limit = zgrid;
     return check_launch(launch_fft(L, s), "fft_rows");
 }
@@ -353,7 +353,7 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
         L.rot.a0 = (int)p->sx.start(p->me);
         (packed_side_is_out ? L.rot.out_mode : L.rot.in_mode) = 1;
     }
-    static const int ygrid = env_grid("DFFT_Y_GRID");
+    const int ygrid = env_grid("DFFT_Y_GRID");
     L.grid_limit = ygrid;
     return check_launch(launch_fft(L, p->stream), "Y pass");
 }
@@ -405,7 +405,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
         L.rot.mask = (int)n2 - 1;
         (p->direction == DFFT_FORWARD ? L.rot.in_mode : L.rot.out_mode) = 2;
     }
-    static const int xgrid = env_grid("DFFT_X_GRID");
+    const int xgrid = env_grid("DFFT_X_GRID");
     L.grid_limit = xgrid;
     L.hints |= p->x_hints;
     return check_launch(launch_fft(L, p->stream), "X pass");

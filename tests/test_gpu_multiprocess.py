@@ -306,7 +306,17 @@ def test_overlapped_pipeline_stress_across_processes(gpu, N, world, parts, ypart
     exchange, forward and backward, against the serial pipeline's result bit for bit: buffer reuse across consecutive
     executes, send data still in flight when the next pass starts, early X passes -- the races an asynchronous exchange
     can expose and a host-synchronising one cannot."""
-    outs = _launch(world, [sys.executable, "-c", STRESS_WORKER],
-                   {"DFFT_N": "x".join(map(str, N)), "DFFT_OVERLAP_PARTS": parts, "DFFT_OVERLAP_YPARTS": yparts})
+    env = {"DFFT_N": "x".join(map(str, N)), "DFFT_OVERLAP_PARTS": parts, "DFFT_OVERLAP_YPARTS": yparts}
+    try:
+        outs = _launch(world, [sys.executable, "-c", STRESS_WORKER], env, timeout=240)
+    except AssertionError as e:
+        # Several processes on ONE GPU is this test's own artefact (every rank brings a dozen hardware queues), and once in round 4
+        # the 4-rank case sat for minutes where it normally takes seconds.  A run that did not FINISH is repeated once, with what the
+        # ranks had printed kept in the warning; a rank that exits with a wrong result or an error fails at once, never retried.
+        if "did not finish within" not in str(e):
+            raise
+        import warnings
+        warnings.warn("overlapped stress case timed out once, repeating it:\n" + str(e)[-2000:])
+        outs = _launch(world, [sys.executable, "-c", STRESS_WORKER], env, timeout=300)
     for r, (o, _) in enumerate(outs):
         assert f"STRESS-OK {r}" in o

@@ -663,6 +663,39 @@ def test_rotated_exchange_rows_vs_oracle(gpu, N, P, prec, monkeypatch):
             assert np.array_equal(brot[g][:cnt], bplain[g][:cnt]), f"backward N={N} P={P} flags={flags} dev={g}"
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("N,P", [((2048, 8, 32), 1), ((2048, 8, 32), 2), ((8, 2048, 32), 1), ((16, 2048, 32), 2)])
+def test_2048_point_tiles_for_every_tile_count(gpu, N, P, prec, monkeypatch):
+    """The 2048-point kernels (paired half-line tiles of the transposing X pass, DIF-split full-line tiles of the other column
+    passes) are persistent: a workgroup's first, later and last tiles take different paths through the loop (more so in the
+    software-pipelined builds, -DDFFT_DUAL_PIPELINE=1 / -DDFFT_DIF2_PIPELINE=1, whose register layout alternates from tile to tile).
+    DFFT_X_GRID / DFFT_Y_GRID cap the persistent grid: 1, 2, 3 and 5 workgroups give every workgroup several tiles, odd and even
+    counts, unequal shares.  Results must not depend on the grid (bit for bit, both directions, natural and packed / rotated maps)
+    and must match the oracle."""
+    from distributedfft_amd import api
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=2048 + P)
+    ref = so.fftn_reference(x, P)
+    inputs = [x[so.slab_start(n0, P, g):so.slab_start(n0, P, g) + so.slab_size(n0, P, g)] for g in range(P)]
+    scale = max(np.abs(r).max() for r in ref)
+    monkeypatch.setenv("DFFT_ROT", "1")
+    monkeypatch.delenv("DFFT_X_GRID", raising=False)
+    monkeypatch.delenv("DFFT_Y_GRID", raising=False)
+    base, _ = _run_plans(gpu, N, P, prec, x, +1, api.PLAN_INPUT_FROM_IN, inputs)
+    bbase, _ = _run_plans(gpu, N, P, prec, None, -1, api.PLAN_INPUT_FROM_IN, [r for r in ref])
+    for d in range(P):
+        cnt = ref[d].size
+        assert np.abs(base[d][:cnt].reshape(ref[d].shape) - ref[d]).max() / scale < TOL[prec], (N, P, d)
+    for grid in ("1", "2", "3", "5"):
+        monkeypatch.setenv("DFFT_X_GRID", grid)
+        monkeypatch.setenv("DFFT_Y_GRID", grid)
+        got, _ = _run_plans(gpu, N, P, prec, x, +1, api.PLAN_INPUT_FROM_IN, inputs)
+        bgot, _ = _run_plans(gpu, N, P, prec, None, -1, api.PLAN_INPUT_FROM_IN, [r for r in ref])
+        for d in range(P):
+            assert np.array_equal(got[d][:ref[d].size], base[d][:ref[d].size]), (N, P, prec, grid, d)
+            assert np.array_equal(bgot[d][:inputs[d].size], bbase[d][:inputs[d].size]), (N, P, prec, grid, d, "backward")
+
+
 def test_in_place_plans_and_reload(gpu):
     """out == None / out == in selects the in-place mode (bufferDev2 = in, fft_mpi_3d_api.cpp:68-71); input is captured
     at plan time and can be replaced through bufferDev1 (fftSpeed3d_c2c.cpp:78) for repeated executes."""
