@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <numeric>
 #include <thread>
 
 #include "dfft_internal.h"
@@ -1236,7 +1237,28 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         long long   mb = p->zy_on ? 230 : 256;
         const char* ce = getenv("DFFT_CHUNK_MB");
         if (ce) mb = atoll(ce);
-        if (mb > 0) {
+        const char* re = getenv("DFFT_CHUNK_RULE");  // 0: the rule of rounds 2-3 for every plan (A/B switch)
+        const bool  y_streams_out = p->exch && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL));
+        if (mb > 0 && !p->zy_on && y_streams_out && !(re && *re == '0')) {
+            // Fused P > 1 plans on two launches per chunk (round 4, profiles/r04/experiments/chunk_rule.log): the Y pass packs its
+            // results straight into the send buffer with streaming stores, so the chunk is only READ from the cache and may fill it
+            // (no head-room), and the largest chunk whose column tiles are a whole number of grid rounds (one tile per CU and round)
+            // beats evened-out chunks, a short last chunk included -- a launch's ramp is amortised over more bytes.  Per rank, t0 /
+            // back-to-back ms: config 4 at P = 8 (128 planes of 6 MiB) 4 x 32 -> 3 x 40 + 8 planes 0.613 / 0.953 -> 0.585 / 0.924, at
+            // P = 4 1.190 / 1.890 -> 1.150 / 1.848; config 5 at P = 8 (16 MiB planes) 15 -> 16 planes 3.298 / 5.157 -> 3.207 / 5.060;
+            // 1024^3 fp64 at P = 8 1.602 / 2.563 -> 1.544 / 2.486.  Single-GPU plans, whose Y pass works in place on the chunk, lose
+            // with it (512^3 on two launches 8 x 64 -> 9 x 60 planes t0 1.380 -> 1.405 ms, 512 x 2048 x 512 6.21 -> 6.80) and keep the
+            // rule below.
+            const long long eb = (long long)elem_bytes(dtype);
+            long long       fit = std::max(1ll, (mb << 20) / (n1 * n2 * eb));
+            const long long line = 128 / eb, cus = std::max(1ll, zy_grid());  // (CUs of the current device)
+            if (n2 % line == 0) {
+                const long long tiles_per_plane = n2 / line;
+                const long long q = cus / std::gcd(cus, tiles_per_plane);  // planes per whole number of grid rounds
+                if (q > 1 && fit >= 2 * q) fit -= fit % q;
+            }
+            p->chunk_planes = fit;
+        } else if (mb > 0) {
             const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
             long long       fit = std::max(1ll, (mb << 20) / plane_b);
             if (plane_b >= (8ll << 20) && fit > 1) --fit;

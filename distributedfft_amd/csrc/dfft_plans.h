@@ -10,6 +10,17 @@
 // upload); contiguous rows of 4096 and 3125 points use plans of their own (dfft_fft_inst.hip: 8 and 5 points per thread).
 #pragma once
 
+// 768 points (config 4's Y axis): 24 points x 32 threads per column -- a 256-thread workgroup per 8-column tile.  -DDFFT_768_E12=1 builds
+// the measurement variant 12 points x 64 threads (512-thread workgroups, radix 4 4 4 4 3: one exchange more).
+#ifndef DFFT_768_E12
+#define DFFT_768_E12 0
+#endif
+#if DFFT_768_E12
+#define DFFT_PLAN_768(X) X(768, 4, 12, 4, 4, 4, 4, 3)
+#else
+#define DFFT_PLAN_768(X) X(768, 4, 24, 8, 8, 4, 3)
+#endif
+
 #define DFFT_PLAN_TABLE(X)        \
     X(2, 0, 2, 2)                 \
     X(3, 0, 3, 3)                 \
@@ -38,7 +49,7 @@
     X(343, 2, 7, 7, 7, 7)         \
     X(384, 3, 24, 8, 8, 3, 2)     \
     X(512, 3, 8, 8, 8, 8)         \
-    X(768, 4, 24, 8, 8, 4, 3)     \
+    DFFT_PLAN_768(X)              \
     X(1024, 5, 16, 8, 8, 8, 2)    \
     X(2048, 6, 16, 8, 8, 8, 4)    \
     X(40, 7, 20, 5, 4, 2)         \
