@@ -27,6 +27,11 @@ template <int N> struct PlanRows : PlanFor<N> {};
 template <int N> struct PlanRows32 : PlanFor32<N> {};
 template <> struct PlanRows<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
 template <> struct PlanRows32<2048> { using type = Plan<2048, 32, 8, 8, 8, 4>; };
+// 768 contiguous points: 12 points x 64 threads -- one wavefront per row, radix 4 4 4 4 3 -- instead of the table's 24 x 32 (round 4,
+// profiles/r04/experiments/lib_ab_768_e12.log, rows_768_e12.log: t0 of 512 x 512 x 768 fp64 2.26 -> 2.17 ms, 768^3 5.54 -> 5.26; as a column
+// length the 24-point plan stays -- config 4's Y axis measured equal)
+template <> struct PlanRows<768> { using type = Plan<768, 12, 4, 4, 4, 4, 3>; };
+template <> struct PlanRows32<768> { using type = Plan<768, 12, 4, 4, 4, 4, 3>; };
 // 3125 contiguous points: 625 threads x 5 points instead of 125 x 25 (two workgroups = 20 waves per CU instead of 4)
 template <> struct PlanRows<3125> { using type = Plan<3125, 5, 5, 5, 5, 5, 5>; };
 template <> struct PlanRows32<3125> { using type = Plan<3125, 5, 5, 5, 5, 5, 5>; };
