@@ -11,7 +11,7 @@
 // preceded this file.  The inverse transform runs the mirror image (column units first, then row units into the result buffer).
 //
 // The arithmetic is the library's own (run_stages of dfft_fft_impl.h with the same plans and register twiddles): the eager-publish
-// kernel is bit-identical to the two-launch path, the lazy-publish one (the default for single-GPU plans, see LAZY below) agrees
+// kernel is bit-identical to the two-launch path, the lazy-publish one (the default, see LAZY below) agrees
 // with it to the last bit or two and is deterministic -- tests/test_gpu_parity.py::test_one_launch_t0_is_bit_identical.
 //
 // Deadlock freedom: tickets are taken in order by RUNNING workgroups only; a producer unit never waits; a consumer unit waits only
@@ -28,8 +28,8 @@
 // Scope: fp64, Y and Z lengths of 256 or 512 points (one wavefront per row FFT, 8 points per thread on both axes); single-GPU fused
 // plans (hand-over buffer or bufferDev1 as w) and P > 1 fused plans with even splits (the Y side then reads / writes the packed,
 // row-rotated exchange layout), whole slabs or the X-plane parts of the overlapped pipeline.  Everything else keeps the chunk loop.
-// The plan uses the stage by itself for 512 x 512-point planes only: with a 256-point axis in the plane two launches per chunk are
-// faster (dfft_plan.cpp, profiles/r03/experiments/variant_ab_256.log).
+// The plan uses the stage by itself on every single-GPU plan it is built for (since round 4: two-line column tiles for 256-point Y
+// axes, ZyTile below) and on P > 1 plans with 512 x 512-point planes (dfft_plan.cpp, profiles/r04/README.md sections 1-2).
 #include "dfft_fft_impl.h"
 #include "dfft_zy.h"
 
