@@ -781,17 +781,19 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 // (a wave touches whole lines), and the two 4-column transforms go through the one LDS tile one after the other while the
 // other half waits in registers.  Fast path of the transposing store only (forward X pass; no ragged tile, no uneven slab),
 // staged per half through the same LDS; everything else stays on fft_tiles_kernel.
-template <class V, class P, int CB> struct DualGeom {
+// WPC: workgroups meant to be resident per CU (each gets 160 KiB / WPC of LDS and 512 / WPC registers per lane)
+template <class V, class P, int CB, int WPC = 1> struct DualGeom {
     using W = typename VecTraits<V>::W;
     static constexpr int    LANES = VecTraits<V>::LANES, OPAD = LANES == 2 ? 2 : 1;
+    static constexpr size_t BUDGET = 160 * 1024 / WPC;
     static constexpr size_t TW_BYTES = ((size_t)P::N * sizeof(W) + 15) / 16 * 16;
-    static constexpr bool   PADROW = (size_t)(P::N + OPAD) * CB * sizeof(V) + TW_BYTES <= 160 * 1024;
+    static constexpr bool   PADROW = (size_t)(P::N + OPAD) * CB * sizeof(V) + TW_BYTES <= BUDGET;
     static constexpr int    ROW = PADROW ? P::N + OPAD : P::N;  // in units of W; CB * LANES rows
     static constexpr size_t LDS_BYTES = TW_BYTES + (size_t)ROW * CB * sizeof(V);
-    static_assert(LDS_BYTES <= 160 * 1024, "dual tiles: tile + twiddle table must fit the CU's LDS");
+    static_assert(LDS_BYTES <= BUDGET, "dual tiles: tile + twiddle table must fit the workgroup's share of the CU's LDS");
 };
-template <class V, class P, int CB, int DIR, bool NT, bool ROT = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * P::T), amdgpu_waves_per_eu(1)))
+template <class V, class P, int CB, int DIR, bool NT, bool ROT = false, int WPC = 1>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * P::T), amdgpu_waves_per_eu(WPC)))
 fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
                       double scale, RotMap rm) {
@@ -805,7 +807,7 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     // 160 KiB, so the rows stay N long and row s is rotated by ROT * s elements instead.  Measured
     // (profiles/r02/experiments/dual_tiles.log): any rotation that is not a multiple of 8 memory elements gives 4.8-4.9 TB/s,
     // multiples of 8 (8, 16) 4.5.
-    using DG = DualGeom<V, P, CB>;
+    using DG = DualGeom<V, P, CB, WPC>;
     constexpr bool PADROW = DG::PADROW;
     constexpr int  ROW = DG::ROW, IMGROT = LANES;
     auto img_at = [](int col, int e) -> int {  // element e of scalar column col, in units of W
@@ -1267,12 +1269,12 @@ hipError_t launch_variant(const FftLaunch& L, hipStream_t stream, int* blocks_pe
     return hipSuccess;
 }
 
-template <class V, class P, int CB, int DIR, bool NT, bool ROT = false> hipError_t launch_dual(const FftLaunch& L, hipStream_t stream) {
+template <class V, class P, int CB, int DIR, bool NT, bool ROT = false, int WPC = 1> hipError_t launch_dual(const FftLaunch& L, hipStream_t stream) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
-    constexpr size_t LDS_BYTES = DualGeom<V, P, CB>::LDS_BYTES;
-    auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT, ROT>;
+    constexpr size_t LDS_BYTES = DualGeom<V, P, CB, WPC>::LDS_BYTES;
+    auto kern = fft_dual_tiles_kernel<V, P, CB, DIR, NT, ROT, WPC>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int         dev = 0;
@@ -1288,7 +1290,7 @@ template <class V, class P, int CB, int DIR, bool NT, bool ROT = false> hipError
     const long long tiles_per_a = L.ncols / (2 * CB), ntiles = L.na * tiles_per_a;
     if (ntiles <= 0) return hipSuccess;
     if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
-    long long grid = device_info().cus;
+    long long grid = (long long)device_info().cus * WPC;
     if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
     if (grid > ntiles) grid = ntiles;
     (void)hipGetLastError();
@@ -1430,6 +1432,25 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
         // when columns are adjacent in memory on the input side (forward X pass)
         constexpr bool can_dual = P::S > 1 && sizeof(V) == 16 && 2 * CBC * sizeof(V) == 128 && (P::N & (P::N - 1)) == 0 && (P::N / VecTraits<V>::LANES) % (CBC * P::T) == 0 &&
                                   (size_t)P::N * CBC * sizeof(V) + (size_t)P::N * sizeof(typename VecTraits<V>::W) <= 160 * 1024;
+        // 1024 points (round 4, -DDFFT_DUAL_1024=1): the full-line tile (128 KiB + table) leaves one 512-thread workgroup per CU; paired
+        // half-line tiles of 4 columns need 64 KiB + table = 80 KiB and 256 threads, so TWO workgroups are resident per CU and one
+        // transforms while the other one's loads and stores are in flight (each still fetches whole 128-byte lines: it owns both
+        // tiles of a line).  Measured and NOT adopted (900 parity cases green; profiles/r04/experiments/lib_ab_dual_1024_two_per_cu.log):
+        // slower everywhere -- config 4's shape X pass 2.72 -> 3.27 ms, fp32 1.19 -> 1.60, its rank at P = 8 0.373 -> 0.392: two resident
+        // workgroups that each have nothing in flight underneath their transforms lose to one workgroup with a whole-tile prefetch.
+#ifndef DFFT_DUAL_1024
+#define DFFT_DUAL_1024 0
+#endif
+        constexpr bool can_dual2 = DFFT_DUAL_1024 && P::N == 1024 && P::E == 16 && sizeof(V) == 16 && (P::N / VecTraits<V>::LANES) % (4 * P::T) == 0;
+        if constexpr (can_dual2) {
+            constexpr int CBH = 4;
+            const bool    transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
+            if (!general && transposed && L.imap.blk % P::T == 0 && L.ncols % (2 * CBH) == 0 && L.imap.cstride == 1 && L.itile.b_stride == 1 &&
+                (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
+                if (rot) return L.dir > 0 ? launch_dual<V, P, CBH, +1, true, true, 2>(L, stream) : launch_dual<V, P, CBH, -1, true, true, 2>(L, stream);
+                return L.dir > 0 ? launch_dual<V, P, CBH, +1, true, false, 2>(L, stream) : launch_dual<V, P, CBH, -1, true, false, 2>(L, stream);
+            }
+        }
         if constexpr (can_dual) {
             static const bool no_dual = [] {  // DFFT_NO_DUAL=1: A/B switch for measurements
                 const char* e = getenv("DFFT_NO_DUAL");
@@ -1462,9 +1483,13 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
             // (the kernel keeps its per-point block offsets in 32 bits)
             const bool fits32 = axis_max_offset(L.imap, P::N) < (1ll << 32) && axis_max_offset(L.omap, P::N) < (1ll << 32);
             const bool rot_tile = rot && L.rot.in_mode != 2 && L.rot.out_mode != 2;  // whole tiles move (Y passes)
-            static const int dif2_min = [] {  // DFFT_DIF2_MIN=<n>: lengths from n on use the split (default 2048; 1024 has a half plan too)
+            // DFFT_DIF2_MIN=<n>: lengths from n on use the split.  Default 1024 since round 4 (two 512-point halves through a 64 KiB
+            // tile): t0 -2 ... -3 % wherever the Y axis is 1024 points long (1024^3 fp32 6.11 -> 5.93 ms, 512 x 1024 x 512 fp64 2.97 ->
+            // 2.90), backward plans unchanged within the noise; 916 parity cases (profiles/r04/experiments/dif2_1024_point_*.log).
+            // DFFT_DIF2_MIN=2048 restores the 16-point-per-thread full-line kernel for 1024 points.
+            static const int dif2_min = [] {
                 const char* e = getenv("DFFT_DIF2_MIN");
-                return e ? atoi(e) : 2048;
+                return e ? atoi(e) : 1024;
             }();
             if (!no_dif2 && P::N >= dif2_min && lines_in && (lines_out || transposed_out) && even && fits32 && L.imap.blk % PH::T == 0 &&
                 L.omap.blk % (2 * PH::T) == 0 && (!rot || rot_tile)) {

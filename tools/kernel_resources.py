@@ -34,7 +34,7 @@ def kernel_table(group: int):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
         mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)(?:ILi\d+EE)?EEEv", name)
-        md = re.match(r"_ZN4dfft21fft_dual_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])E(?:Lb([01])E)?EEv", name)
+        md = re.match(r"_ZN4dfft21fft_dual_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])E(?:Lb([01])E)?(?:Li(\d+)E)?EEv", name)
         if mm:
             ty = TYPES.get(mm.group(1), mm.group(1))
             tag = (f"{ty} N={mm.group(2)} E={mm.group(3)} CB={mm.group(4)} G={mm.group(5)} dir={'-1' if mm.group(6) == 'n1' else '1'} "
@@ -42,7 +42,7 @@ def kernel_table(group: int):
         elif md:  # paired half-line tiles (transposing store of the 2048-point X pass)
             ty = TYPES.get(md.group(1), md.group(1))
             tag = (f"{ty} N={md.group(2)} E={md.group(3)} CB=2x{md.group(4)} G=1 dir={'-1' if md.group(5) == 'n1' else '1'} general=0 DualTiles"
-                   f"{' rotated-rows' if md.group(7) == '1' else ''}")
+                   f"{' rotated-rows' if md.group(7) == '1' else ''}{' x' + md.group(8) + ' per CU' if md.group(8) and md.group(8) != '1' else ''}")
         elif "fft_dif2_tiles_kernel" in name:  # DIF-split full-line tiles (non-transposing 2048-point column passes)
             mh = re.match(r"_ZN4dfft21fft_dif2_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])ELb([01])E", name)
             if not mh:

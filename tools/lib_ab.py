@@ -36,7 +36,9 @@ for spec in specs:
     a = (torch.rand(mc, generator=g, device=dev, dtype=torch.float32) - 0.5).to(cdt)
     b = torch.zeros_like(a)
     comm = api.Comm.local(P) if P > 1 else None
-    p = api.Plan(n0, n1, n2, a, b, comm, 0, P, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+    direction = api.BACKWARD if os.environ.get("DFFT_AB_DIR") == "-1" else api.FORWARD  # (backward: the four stage times are printed in execution order)
+    extra = api.PLAN_UNFUSED if os.environ.get("DFFT_AB_UNFUSED") == "1" else 0  # (the reference's stage structure: separate pack / transpose launches)
+    p = api.Plan(n0, n1, n2, a, b, comm, 0, P, direction, api.PLAN_INPUT_FROM_IN | extra)
     if P == 1:
         p.tune()
     for _ in range(6):
@@ -57,7 +59,8 @@ for spec in specs:
     pipelined = (time.perf_counter() - t_host) / K * 1e3
     bytes_pass = 2.0 * S * n0 * n1 * n2 / P
     print(f"{Path(lib).name:28s} {spec:44s} sha {digest}  t0 {m[0]:.4f}  t3 {m[3]:.4f}  X pass {bytes_pass / m[3] / 1e6:.0f} GB/s"
-          f"  t0 as two passes {2 * bytes_pass / m[0] / 1e6:.0f} GB/s  back-to-back {pipelined:.4f}  [{p.describe()}]", flush=True)
+          f"  t0 as two passes {2 * bytes_pass / m[0] / 1e6:.0f} GB/s  back-to-back {pipelined:.4f}  [{p.describe()}]"
+          + (f"  backward stages {m[0]:.4f} {m[1]:.4f} {m[2]:.4f} {m[3]:.4f}" if direction == api.BACKWARD else ""), flush=True)
     p.destroy()
     if comm:
         comm.destroy()
