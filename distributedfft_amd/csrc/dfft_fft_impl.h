@@ -1194,6 +1194,123 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Column tiles whose INPUT side is the transposed one ([..][z][kx], kx fastest: the inverse X pass; reference fftX backward,
+// fft_mpi_3d_api.cpp:553-570) -- the mirror image of the staged transposing store of fft_tiles_kernel (round 4).  On that side
+// the columns of a tile are far apart and the FFT index is the contiguous one, so fft_tiles_kernel reads 128-byte pieces in fp64
+// and cannot use column pairs at all in fp32 (two adjacent columns are not adjacent in memory: those launches ran on the scalar
+// float2 kernel at half the rate).  Here a thread loads 16-byte memory elements in LINEAR order of the [scalar column][kx] tile
+// (a wave reads 1 KiB runs), the workgroup stages them through an LDS image with one row per scalar column, and every thread
+// picks its points j + T k of its column (pair) out of the image; the transform and the plain contiguous-column store are those of
+// fft_tiles_kernel.  Single-block maps on both sides, whole tiles, one tile per workgroup at a time (fast path only); the output side
+// may carry rotated rows per point (RotMap mode 2: the send buffer of a P > 1 backward plan).
+// imap: stride 1 per MEMORY ELEMENT along kx, cstride per SCALAR column; itile: a_stride per slice, b_stride per column of V.
+struct TuneTransposedLoad : TuneDefault {
+    static constexpr bool OSTAGE = true;  // (sizes the LDS for the image: the same [CB * LANES][N + OPAD] rows as the staged store)
+};
+template <class V, class P, int CB, int DIR, bool ROT>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * P::T), amdgpu_waves_per_eu(1)))
+fft_tload_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
+                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
+                       double scale, RotMap rm) {
+    using KG = KernelGeom<V, P, CB, 1, TuneTransposedLoad>;
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr int E = P::E, T = P::T, GT = CB * T, N = P::N, LANES = VT::LANES, ON = N / LANES, ROW = N + KG::OPAD;
+    static_assert(KG::OSTAGE && KG::PH == 1 && !KG::PAD && !KG::WAVE_LOCAL, "transposed load: multi-stage plans on block-wide one-phase tiles");
+    static_assert(ON % GT == 0 || GT % ON == 0, "transposed load: power-of-two geometry");
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    W* ldstw = reinterpret_cast<W*>(dfft_smem);
+    V* lds = reinterpret_cast<V*>(dfft_smem + KG::TW_BYTES);
+    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    constexpr int TWN = KG::TWMODE == TW_REG ? KG::TWN : 0;
+    W        twreg[TWN > 0 ? TWN : 1];
+    const W* twr = twreg;
+    if constexpr (KG::TWMODE == TW_GLOBAL) {
+        twr = tw;
+    } else if constexpr (KG::TWMODE == TW_LDS) {
+#if DFFT_TW_STAGE_MAJOR
+        fill_stage_major<W, P, 0, DIR>(ldstw, tw, tid, GT);
+#else
+        for (int i = tid; i < N; i += GT) {
+            W w = tw[i];
+            if (DIR < 0) w.y = -w.y;
+            ldstw[i] = w;
+        }
+#endif
+        __syncthreads();
+        twr = ldstw;
+    } else {
+        load_twiddles<W, P, 0, DIR, TuneTransposedLoad::TWPOW>(twreg, tw, j);
+    }
+    constexpr bool TWPOW = TuneTransposedLoad::TWPOW && KG::TWMODE == TW_REG;
+    // load step k: linear element tid + GT k of the tile = memory element (lin % ON) of scalar column lin / ON
+    const long long ibase = ON % GT == 0 ? (long long)tid : (long long)(tid % ON) + (long long)(tid / ON) * imap.cstride;
+    auto in_off = [&](int k) -> long long {
+        const int oc = (GT * k) / ON;  // exact in both cases
+        return ibase + (ON % GT == 0 ? (GT * k) % ON : 0) + (long long)oc * imap.cstride;
+    };
+    const int scol0 = ON % GT == 0 ? 0 : tid / ON, se0 = ON % GT == 0 ? tid : tid % ON;  // image position of load step 0
+    const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+    const unsigned or0 = (unsigned)(j * omap.stride + c * omap.cstride), ostep = (unsigned)(T * omap.stride);
+    const int rot_j = ROT ? (rm.rot * j) & rm.mask : 0, rot_t = ROT ? (rm.rot * T) & rm.mask : 0;
+    auto in_ptr = [&](unsigned t) -> const GV* {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        return in + (long long)a * itile.a_stride + (long long)(b * CB) * itile.b_stride;
+    };
+    GV raw[E], rawn[E];
+    unsigned t = blockIdx.x;
+    if (t < ntiles) {
+        const GV* ip = in_ptr(t);
+#pragma unroll
+        for (int k = 0; k < E; ++k) raw[k] = gload<true>(ip + in_off(k));
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const unsigned tn = t + gridDim.x;
+        if (tn < ntiles) {  // the next tile's loads complete underneath this tile's exchanges
+            const GV* ip = in_ptr(tn);
+#pragma unroll
+            for (int k = 0; k < E; ++k) rawn[k] = gload<true>(ip + in_off(k));
+        }
+        W* img = reinterpret_cast<W*>(lds);
+        __syncthreads();  // the previous tile's last exchange is no longer read
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int col = scol0 + (GT * k) / ON, e = se0 + (ON % GT == 0 ? (GT * k) % ON : 0);
+            *reinterpret_cast<GV*>(img + col * ROW + e * LANES) = raw[k];
+        }
+        __syncthreads();
+        V v[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            if constexpr (LANES == 2) {
+                const W a0 = img[(c * 2) * ROW + j + T * k], a1 = img[(c * 2 + 1) * ROW + j + T * k];
+                v[k] = VT::from_g(GV{a0.x, a0.y, a1.x, a1.y});
+            } else {
+                v[k] = img[c * ROW + j + T * k];
+            }
+        }
+        __syncthreads();  // the image is read before the first exchange overwrites it
+        run_stages<V, P, 0, DIR, CB, false, false, KG::TWMODE, TWPOW, 1>(v, twr, lds, j, c);
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        const int      ob0 = (int)(b * CB);
+        GV*            op = out + (long long)a * otile.a_stride + (long long)ob0 * otile.b_stride;
+        unsigned       o0 = or0;
+        asm volatile("" : "+v"(o0));  // per tile, not a loop invariant (see fft_tiles_kernel)
+        // the prefetched tile is waited for BEFORE this tile's stores are issued (it has had the exchanges to arrive), so that the
+        // stores drain underneath the next tile instead of in front of it (one vmcnt for loads and stores)
+#pragma unroll
+        for (int k = 0; k < E; ++k) raw[k] = rawn[k];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            long long off = (long long)(o0 + (unsigned)k * ostep);
+            if constexpr (ROT) off += (long long)(((ob0 + rot_j + k * rot_t) & rm.mask) - ob0);
+            gstore<false>(op + off, VT::to_g(cscale(v[k], sc)));
+        }
+    }
+}
+
 struct DeviceInfo {
     int cus;
 };
@@ -1338,6 +1455,44 @@ template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool
     return hipSuccess;
 }
 
+template <class V, class P, int CB, int DIR, bool ROT> hipError_t launch_tload(const FftLaunch& L, hipStream_t stream) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    using KG = KernelGeom<V, P, CB, 1, TuneTransposedLoad>;
+    constexpr size_t LDS_BYTES = KG::LDS_BYTES;
+    auto kern = fft_tload_tiles_kernel<V, P, CB, DIR, ROT>;
+    static std::atomic<int> blocks_per_cu[64];  // 0 = not set up on that device yet
+    static std::mutex       setup_mutex;
+    int         dev = 0;
+    hipError_t  e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * P::T);
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, CB * P::T, LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
+    }
+    const long long tiles_per_a = L.ncols / CB, ntiles = L.na * tiles_per_a;
+    if (ntiles <= 0) return hipSuccess;
+    if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    long long grid = (long long)device_info().cus * blocks_per_cu[dev].load(std::memory_order_relaxed);
+    if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
+    if (grid > ntiles) grid = ntiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * P::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
+    e = hipGetLastError();
+    if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * P::T);
+    return hipSuccess;
+}
+
 template <int X> struct ConstMax1 { static constexpr int value = X < 1 ? 1 : X; };
 
 // Columns per tile for the column kernel: a full 128-byte line per row segment (8 fp64 / 16 fp32 complex).  Tiles up to
@@ -1367,6 +1522,37 @@ template <class V, class P> constexpr bool can_stage_store() {
     constexpr int PH = (size_t)P::N * CBC * sizeof(V) > 128 * 1024 ? 2 : 1;  // KernelGeom::PH
     return P::S > 1 && CBC * (int)sizeof(V) >= (L == 2 ? 64 : 128) && P::N % L == 0 &&
            (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC / PH * GC * sizeof(V) <= 144 * 1024;
+}
+
+// the staged transposed LOAD (fft_tload_tiles_kernel) exists where the staged store's image fits, on one-phase tiles of at least 256
+// threads whose linear element order splits evenly over the workgroup.  -DDFFT_TLOAD=0 compiles the path out (A/B builds).
+#ifndef DFFT_TLOAD
+#define DFFT_TLOAD 1
+#endif
+template <class V, class P> constexpr bool can_tload() {
+    constexpr int CBC = cols_per_tile<V, P>();
+    constexpr int GT = CBC * P::T, ON = P::N / VecTraits<V>::LANES;
+    // fp32 column pairs always (their alternative is the scalar kernel); fp64 only up to 256 points -- measured (round 4,
+    // profiles/r04/experiments/lib_ab_transposed_load.log, backward plans, inverse X pass): fp32 1024^3 7.38 -> 4.02 ms, config 5's rank
+    // at P = 8 3.65 -> 2.62, 512^3 fp32 0.52 -> 0.455; fp64 256^3 0.1045 -> 0.0893 but 512^3 0.84 -> 0.99 and 1024 x 768 x 512 2.49 ->
+    // 2.76 (fp64 already reads whole lines through fft_tiles_kernel and pays here for the extra LDS round trip).
+    constexpr bool type_ok = VecTraits<V>::LANES == 2 || P::N <= 256;
+    return DFFT_TLOAD && type_ok && sizeof(V) == 16 && P::S > 1 && can_stage_store<V, P>() && GT >= 256 && GT <= 1024 && (ON % GT == 0 || GT % ON == 0) &&
+           (size_t)P::N * CBC * sizeof(V) <= 128 * 1024;
+}
+// run-time side of the same rule (fast path only: single-block maps, whole tiles, rotation -- if any -- per point on the output side)
+template <class V, class P> bool tload_applies(const FftLaunch& L) {
+    if constexpr (!can_tload<V, P>()) {
+        return false;
+    } else {
+        constexpr int CBC = cols_per_tile<V, P>();
+        const bool    general = (L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0;
+        const bool    tin = L.imap.nblk == 1 && L.imap.sub <= 1 && L.imap.stride == 1 && L.imap.cstride != 1;
+        const bool    cout_ = L.omap.nblk == 1 && L.omap.sub <= 1 && L.omap.cstride == 1 && L.otile.b_stride == 1;
+        const bool    rot = L.rot.in_mode != 0 || L.rot.out_mode != 0;
+        const bool    rot_ok = !rot || (L.rot.in_mode == 0 && L.rot.out_mode == 2);
+        return !general && tin && cout_ && rot_ok && axis_max_offset(L.omap, P::N) < (1ll << 32);
+    }
 }
 
 // Column launches describe the work as `na` slices of `ncols` columns; the tile geometry follows from the variant's CB.
@@ -1411,6 +1597,17 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
         if (!ok) return hipErrorInvalidValue;
     }
     if constexpr (CBC * P::T <= 1024) {
+        // transposed INPUT side (the inverse X pass): staged load
+        if constexpr (can_tload<V, P>()) {
+            if (tload_applies<V, P>(L)) {
+                if (rot) return L.dir > 0 ? launch_tload<V, P, CBC, +1, true>(L, stream) : launch_tload<V, P, CBC, -1, true>(L, stream);
+                return L.dir > 0 ? launch_tload<V, P, CBC, +1, false>(L, stream) : launch_tload<V, P, CBC, -1, false>(L, stream);
+            }
+        }
+        if constexpr (VecTraits<V>::LANES == 2) {  // column pairs reach a transposed input side only through that kernel (make_pair_launch)
+            if (L.imap.nblk == 1 && L.imap.stride == 1 && L.imap.cstride != 1 && !(L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1))
+                return hipErrorInvalidValue;
+        }
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
         using TTF = TuneTransposedStoreFull;
@@ -1607,7 +1804,23 @@ template <class P> bool make_pair_launch(const FftLaunch& L, FftLaunch& out) {
         to.b_stride = 1;
         return true;
     };
-    if (!contiguous(L.imap, L.itile, out.imap, out.itile)) return false;
+    if (!contiguous(L.imap, L.itile, out.imap, out.itile)) {
+        // transposed input side (unit stride along the FFT index, columns far apart: the inverse X pass): only through the staged
+        // load, whose map is (memory element along kx, scalar column) -- fft_tload_tiles_kernel
+        if constexpr (can_tload<cpair, P>()) {
+            if (!contiguous(L.omap, L.otile, out.omap, out.otile)) return false;
+            if (L.imap.nblk != 1 || L.imap.sub > 1 || L.imap.stride != 1 || L.imap.cstride == 1 || L.imap.last_delta != 0 || (L.imap.blk & 1)) return false;
+            if (!even(L.imap.cstride) || !even(L.itile.a_stride) || !even(L.itile.b_stride)) return false;
+            out.imap = L.imap;
+            out.imap.blk = L.imap.blk / 2;           // memory elements along the FFT index
+            out.imap.stride = 1;
+            out.imap.cstride = L.imap.cstride / 2;   // per scalar column
+            out.itile.a_stride = L.itile.a_stride / 2;
+            out.itile.b_stride = L.itile.b_stride;   // per PAIR of columns = 2 * (b_stride / 2)
+            return tload_applies<cpair, P>(out);
+        }
+        return false;
+    }
     if (contiguous(L.omap, L.otile, out.omap, out.otile)) return true;
     // transposed output side (unit stride along the FFT index, columns far apart): only through the staged store, whose
     // map is (memory element along kx, scalar column) -- see fft_tiles_kernel

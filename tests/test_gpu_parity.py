@@ -664,11 +664,14 @@ def test_rotated_exchange_rows_vs_oracle(gpu, N, P, prec, monkeypatch):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
-@pytest.mark.parametrize("N,P", [((2048, 8, 32), 1), ((2048, 8, 32), 2), ((8, 2048, 32), 1), ((16, 2048, 32), 2)])
+@pytest.mark.parametrize("N,P", [((2048, 8, 32), 1), ((2048, 8, 32), 2), ((8, 2048, 32), 1), ((16, 2048, 32), 2), ((1024, 8, 32), 1),
+                                 ((1024, 16, 32), 2), ((512, 16, 32), 1), ((256, 16, 64), 2)])
 def test_2048_point_tiles_for_every_tile_count(gpu, N, P, prec, monkeypatch):
     """The 2048-point kernels (paired half-line tiles of the transposing X pass, DIF-split full-line tiles of the other column
     passes) are persistent: a workgroup's first, later and last tiles take different paths through the loop (more so in the
     software-pipelined builds, -DDFFT_DUAL_PIPELINE=1 / -DDFFT_DIF2_PIPELINE=1, whose register layout alternates from tile to tile).
+    The same holds for the staged transposed LOAD of the inverse X pass (fft_tload_tiles_kernel: fp32 column pairs of 256 ... 2048
+    points, fp64 up to 256 points), which prefetches the next tile's raw elements -- the shapes with a 256- / 512- / 1024-point X axis.
     DFFT_X_GRID / DFFT_Y_GRID cap the persistent grid: 1, 2, 3 and 5 workgroups give every workgroup several tiles, odd and even
     counts, unequal shares.  Results must not depend on the grid (bit for bit, both directions, natural and packed / rotated maps)
     and must match the oracle."""

@@ -30,7 +30,7 @@ def kernel_table(group: int):
             raise RuntimeError(r.stderr[-3000:])
         asm = next(Path(tmp).glob("*gfx950.s")).read_text()
     rows = []
-    for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel|21fft_dif2_tiles_kernel)\w+): ", asm, re.M):
+    for m in re.finditer(r"^(_ZN4dfft(?:16fft_tiles_kernel|21fft_dual_tiles_kernel|21fft_dif2_tiles_kernel|22fft_tload_tiles_kernel)\w+): ", asm, re.M):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
         mm = re.match(r"_ZN4dfft16fft_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(\d+)ELi(n?1)ELb([01])ENS_\d+(\w+?)(?:ILi\d+EE)?EEEv", name)
@@ -43,6 +43,13 @@ def kernel_table(group: int):
             ty = TYPES.get(md.group(1), md.group(1))
             tag = (f"{ty} N={md.group(2)} E={md.group(3)} CB=2x{md.group(4)} G=1 dir={'-1' if md.group(5) == 'n1' else '1'} general=0 DualTiles"
                    f"{' rotated-rows' if md.group(7) == '1' else ''}{' x' + md.group(8) + ' per CU' if md.group(8) and md.group(8) != '1' else ''}")
+        elif "fft_tload_tiles_kernel" in name:  # staged transposed load (inverse X pass)
+            mt = re.match(r"_ZN4dfft22fft_tload_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])EEEv", name)
+            if not mt:
+                continue
+            ty = TYPES.get(mt.group(1), mt.group(1))
+            tag = (f"{ty} N={mt.group(2)} E={mt.group(3)} CB={mt.group(4)} G=1 dir={'-1' if mt.group(5) == 'n1' else '1'} general=0 "
+                   f"TransposedLoad{' rotated-rows' if mt.group(6) == '1' else ''}")
         elif "fft_dif2_tiles_kernel" in name:  # DIF-split full-line tiles (non-transposing 2048-point column passes)
             mh = re.match(r"_ZN4dfft21fft_dif2_tiles_kernelI(.*?)NS_4PlanILi(\d+)ELi(\d+)EJ.*?EEELi(\d+)ELi(n?1)ELb([01])ELb([01])E", name)
             if not mh:
