@@ -382,9 +382,15 @@ def main():
     plan_setup = "dfft_plan_create"
     tune_report, plan_desc = None, ""
     if P == 1 and hasattr(plan, "tune"):
+        # This process owns the GPU, so the placement walk may borrow what the library's shared-GPU defaults (a quarter of the free
+        # memory, 32 candidates) do not: on some boxes 60+ GiB of consecutive allocations behave alike (profiles/r04/experiments/
+        # tune_check_short_walk.log: 4 of 10 processes found no fast buffer within 32 candidates and ran at 1.94 instead of 1.87 ms).
+        os.environ.setdefault("DFFT_TUNE_MEM_PCT", "70")
+        os.environ.setdefault("DFFT_TUNE_TRIES", "128")
         plan.tune()  # plan-time measurement (FFTW_MEASURE-style, part of plan set-up, before any warm-up or timed step)
-        plan_setup += (" + dfft_plan_tune (plan-time placement of the hand-over buffer: the X-pass kernel alone timed on a few "
-                       "candidate allocations, before warm-up; results bit-identical without it)")
+        plan_setup += (" + dfft_plan_tune (plan-time placement of the hand-over buffer: the X-pass kernel alone timed on "
+                       "candidate allocations -- up to 128 / 70 % of the free memory, all returned -- before warm-up; results "
+                       "bit-identical without it)")
         if hasattr(plan, "tune_report"):
             tune_report = plan.tune_report()
     if hasattr(plan, "describe"):

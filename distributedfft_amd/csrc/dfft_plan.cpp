@@ -1465,7 +1465,24 @@ int dfft_plan_tune(dfft_plan_t plan) {
     float  lo = ms, hi = ms;
     size_t used = saved_out ? out_bytes : 0;
     while ((int)cand.size() < max_tries && used + spacer_bytes + wbytes <= budget) {
-        if (lo < 0.97f * hi) break;  // both behaviours seen: keep the fast one
+        if (lo < 0.97f * hi) {
+            // Both behaviours seen?  The two classes are 5-8 % apart, but single probes of ONE class have been seen 3.5 % apart (round 4,
+            // profiles/r04/experiments/tune_check_false_stop.log: 0.7841 / 0.8027 / 0.7749 ms, all slow -- the walk stopped there and the
+            // bench process ran at 1.94 instead of 1.87 ms).  So the fastest and the slowest candidate are timed once more, each keeps its
+            // lower figure (a probe reads high more often than low), and only a confirmed gap ends the walk.
+            int ilo = 0, ihi = 0;
+            for (int i = 1; i < (int)p->w_ms.size(); ++i) {
+                if (p->w_ms[i] < p->w_ms[ilo]) ilo = i;
+                if (p->w_ms[i] > p->w_ms[ihi]) ihi = i;
+            }
+            for (int idx : {ilo, ihi}) {
+                float again = 0.f;
+                if (probe_x_pass(p, cand[idx], &again) == DFFT_OK && again > 0.f) p->w_ms[idx] = std::min(p->w_ms[idx], again);
+            }
+            lo = *std::min_element(p->w_ms.begin(), p->w_ms.end());
+            hi = *std::max_element(p->w_ms.begin(), p->w_ms.end());
+            if (lo < 0.965f * hi) break;  // confirmed: keep the fast one
+        }
         void *sp = nullptr, *nw = nullptr;
         if (spacer_bytes > 0) {
             if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
