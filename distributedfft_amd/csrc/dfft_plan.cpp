@@ -482,7 +482,7 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.w = w;
     L.dst = dst;
     L.src_plane = L.dst_plane = p->N[1] * p->N[2];
-    L.w_plane = w_plane;
+    L.w_plane = w_plane; DFFT_ZY_SET_PITCH(L, (p->wbuf && w == p->wbuf) ? p->wl.pitch : p->N[2]);
     L.plane0 = x0;
     L.nplanes = nx;
     L.chunk = zy_phase_planes(p, nx);
@@ -1184,7 +1184,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         const long long ysub = p->sy.blk / std::max(1, p->ycuts);
-        const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2);
+        const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2 || DFFT_ZY_ROW_PITCH);
         const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % (n1 / 8) == 0;  // even splits; a
                                    // destination block is a whole number of the column unit's 8-point-per-thread strides
         // Where the stage is used by itself (DFFT_T0_ONE_LAUNCH=0: never; =1: wherever the kernel exists on single-GPU plans; =all:

@@ -8,6 +8,20 @@ namespace dfft {
 
 enum { ZY_MAX_PLANES = 4096 };
 
+// -DDFFT_ZY_ROW_PITCH=1 (build-time experiment prepared at the end of round 4, compiled but NOT yet run -- no GPU time was left): the row
+// pitch of the hand-over buffer w becomes a launch parameter instead of the compile-time N2, so that a plan whose buffer has padded rows
+// (DFFT_PAD_ROW) can use the one-launch stage.  Meant for BACKWARD single-GPU plans, whose column units read w from HBM at a
+// power-of-two row stride (0.937 against 0.793 ms in round 2's copy experiments of that pattern).  The default
+// build is byte-identical without it (library d7893003).  Build with tools/build_variant.py (it recompiles dfft_plan.cpp too).
+#ifndef DFFT_ZY_ROW_PITCH
+#define DFFT_ZY_ROW_PITCH 0
+#endif
+#if DFFT_ZY_ROW_PITCH
+#define DFFT_ZY_SET_PITCH(L, v) (L).w_pitch = (v)
+#else
+#define DFFT_ZY_SET_PITCH(L, v) ((void)0)  // (keeps dfft_plan.cpp's line numbers -- they are part of its error strings -- and object code as profiled)
+#endif
+
 // why a launch gave up (ZyCtl::error and the host-visible word)
 enum { ZY_ERR_TIMEOUT = 1,   // a consumer unit polled spin_polls times for its plane's producers
        ZY_ERR_DESYNC = 2 };  // the first ticket of a launch did not fit its ticket_base: counters out of step with the host
@@ -29,6 +43,9 @@ struct ZyLaunch {
     void*       w;          // hand-over buffer: rows N2 apart, planes w_plane elements apart
     void*       dst;        // backward: [plane][N1][N2], planes dst_plane elements apart
     long long   src_plane, w_plane, dst_plane;
+#if DFFT_ZY_ROW_PITCH
+    long long   w_pitch;      // distance between consecutive rows of w (elements; >= n2)
+#endif
     long long   plane0, nplanes, chunk;  // first plane and number of planes of this launch; planes per Infinity-Cache phase
     ZyCtl*      ctl;
     unsigned    ticket_base;  // value of ctl->ticket when this launch starts (the host adds zy_tickets() per launch)

@@ -62,7 +62,11 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(ZyTile<PY, PACK>::THREADS, ZyTile<PY, PACK>::THREADS), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
-                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls, unsigned need) {
+                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls, unsigned need
+#if DFFT_ZY_ROW_PITCH
+                , unsigned wpitch
+#endif
+                ) {
     using V = double2;
     constexpr int CB = ZyTile<PY, PACK>::CB;  // columns per tile: one cache line, or two for 256-point Y axes (ZyTile)
     constexpr int THREADS = ZyTile<PY, PACK>::THREADS;
@@ -75,6 +79,12 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     constexpr unsigned UA = DIR > 0 ? UZ : UY, UB = DIR > 0 ? UY : UZ, BB = UA + UB;  // producer / consumer units per plane
     constexpr bool     TWPOW = true;
     constexpr int      ROW_LDS = N2 + N2 / 8;  // padded row (lds_index<1, true>)
+// row pitch of w: the compile-time N2, or the launch parameter of the -DDFFT_ZY_ROW_PITCH=1 build (dfft_zy.h)
+#if DFFT_ZY_ROW_PITCH
+#define DFFT_ZY_WP ((int)wpitch)
+#else
+#define DFFT_ZY_WP N2
+#endif
 
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     unsigned* shw = reinterpret_cast<unsigned*>(dfft_smem);  // [0] ticket broadcast, [1] dependency state
@@ -160,7 +170,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         return ok;
     };
     auto wrsrc = [&](unsigned plane) {  // buffer descriptor of one plane of w (offsets inside a plane fit 32 bits)
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(w + (long long)plane * w_plane), 0, (int)((size_t)N1 * N2 * sizeof(V)), 0x00020000);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(w + (long long)plane * w_plane), 0, (int)((size_t)N1 * DFFT_ZY_WP * sizeof(V)), 0x00020000);
     };
     // packed side (PACK): point jy + TY k of a column lies in block (TY k) / pk.blk of the map -- the launcher guarantees
     // pk.blk % TY == 0, so the block term is wave-uniform per k (computed once) -- plus one per-thread term and the tile's base
@@ -189,7 +199,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((un * GR + gz) * N2 + jz + TZ * k);
+                const unsigned elem = (unsigned)((un * GR + gz) * DFFT_ZY_WP + jz + TZ * k);
                 d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
             }
         }
@@ -199,7 +209,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((un * GR + gz) * N2 + jz + TZ * k);
+                const unsigned elem = (unsigned)((un * GR + gz) * DFFT_ZY_WP + jz + TZ * k);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
             }
         } else {
@@ -214,7 +224,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
+                const unsigned elem = (unsigned)((jy + TY * k) * DFFT_ZY_WP + un * CB + cy);
                 d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
             }
         } else if constexpr (PACK) {
@@ -222,9 +232,9 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 #pragma unroll
             for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + pk_uni[k]);
         } else {
-            const V* ip = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
+            const V* ip = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
-            for (int k = 0; k < E; ++k) d[k] = ip[(long long)(TY * k) * N2];
+            for (int k = 0; k < E; ++k) d[k] = ip[(long long)(TY * k) * DFFT_ZY_WP];
         }
     };
     auto store_cols = [&](unsigned plane, unsigned un, const V* v) {
@@ -233,14 +243,14 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 #pragma unroll
             for (int k = 0; k < E; ++k) gstore<true>(op + pk_uni[k], v[k]);
         } else if constexpr (ROWS_PRODUCE) {
-            V* op = w + (long long)plane * w_plane + (long long)jy * N2 + un * CB + cy;
+            V* op = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
-            for (int k = 0; k < E; ++k) op[(long long)(TY * k) * N2] = v[k];
+            for (int k = 0; k < E; ++k) op[(long long)(TY * k) * DFFT_ZY_WP] = v[k];
         } else {
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
             for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((jy + TY * k) * N2 + un * CB + cy);
+                const unsigned elem = (unsigned)((jy + TY * k) * DFFT_ZY_WP + un * CB + cy);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
             }
         }
@@ -401,7 +411,11 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
                        (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.plane0, (unsigned)L.nplanes,
-                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls, UA + (L.fault ? 1u : 0u));
+                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls, UA + (L.fault ? 1u : 0u)
+#if DFFT_ZY_ROW_PITCH
+                       , (unsigned)L.w_pitch
+#endif
+    );
     return hipGetLastError();
 }
 
@@ -430,6 +444,9 @@ unsigned zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     if (!zy_supported(L.dtype, L.n1, L.n2) || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || L.chunk <= 0 || !L.err_host || L.spin_polls == 0)
         return hipErrorInvalidValue;
+#if DFFT_ZY_ROW_PITCH
+    if (L.w_pitch < L.n2 || (long long)L.n1 * L.w_pitch * 16 >= (1ll << 31)) return hipErrorInvalidValue;  // (32-bit buffer offsets inside a plane)
+#endif
 #define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
         if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream); \
