@@ -73,6 +73,7 @@ SIGNATURES = {
     "dfft_boot_barrier": (C.c_int, []),
     "dfft_boot_allreduce_max": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
     "dfft_boot_finalize": (C.c_int, []),
+    "dfft_trace_dump": (C.c_int, []),
 }
 
 _lib = None

@@ -60,6 +60,24 @@ def _headers():
     return sorted(list(CSRC.glob("*.h")) + list(INCLUDE.glob("*.h")) + list(INCLUDE.glob("*/*.h")))
 
 
+def _deps(src: Path, seen=None):
+    """src and every project header it includes, transitively (quoted includes only): a change to a host-side header
+    must not recompile the twelve kernel instantiation groups."""
+    import re
+    seen = set() if seen is None else seen
+    src = src.resolve()
+    if src in seen or not src.exists():
+        return seen
+    seen.add(src)
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', src.read_text(errors="replace"), re.M):
+        for base in (src.parent, CSRC, INCLUDE):
+            cand = (base / m.group(1))
+            if cand.exists():
+                _deps(cand, seen)
+                break
+    return seen
+
+
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     hdrs = _headers()
@@ -70,12 +88,12 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     units.append((CSRC / "dfft_generic.hip", OBJ / "dfft_generic.o", []))
     units.append((CSRC / "dfft_long.hip", OBJ / "dfft_long.o", []))
     units.append((CSRC / "dfft_zy.hip", OBJ / "dfft_zy.o", []))
-    for name in ("dfft_plan", "dfft_exchange", "dfft_bootstrap", "dfft_alloc"):
+    for name in ("dfft_plan", "dfft_exchange", "dfft_bootstrap", "dfft_alloc", "dfft_trace"):
         units.append((CSRC / f"{name}.cpp", OBJ / f"{name}.o", ["-x", "hip"]))
 
     def compile_one(u):
         src, obj, extra = u
-        if not force and not _newer(obj, [src] + hdrs):
+        if not force and not _newer(obj, _deps(src)):
             return False
         cmd = [HIPCC] + COMMON + extra + ["-c", str(src), "-o", str(obj)]
         if verbose:

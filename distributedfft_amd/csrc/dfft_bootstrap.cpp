@@ -8,6 +8,7 @@
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <unistd.h>
 
@@ -50,20 +51,57 @@ bool send_all(int fd, const void* buf, size_t n) {
     }
     return true;
 }
-bool recv_all(int fd, void* buf, size_t n) {
+// Every wait of the rendezvous is bounded (DFFT_BOOT_TIMEOUT_S, default 180 s; 0 = wait for ever): a peer that died, or that
+// left the collective call sequence, turns into DFFT_ECOMM with the process's last control-plane events on stderr
+// (dfft_trace.cpp) instead of a rank that hangs in recv() -- the MPI calls this layer replaces (fftSpeed3d_c2c.cpp:18-26,
+// 120-124) would hang the same way, which is how round 4's stalled multi-process cases left no trace of their cause.
+int boot_timeout_ms() {
+    static const int ms = [] {
+        const char* e = getenv("DFFT_BOOT_TIMEOUT_S");
+        const double s = e && *e ? atof(e) : 180.0;
+        return s <= 0 ? -1 : (int)(s * 1000.0);
+    }();
+    return ms;
+}
+int  g_recv_state = 0;  // why the last recv_all failed: 1 = time-out, 2 = peer closed the connection, 3 = socket error
+bool recv_all(int fd, void* buf, size_t n, int timeout_ms = -2) {
     char* p = (char*)buf;
+    if (timeout_ms == -2) timeout_ms = boot_timeout_ms();
+    g_recv_state = 0;
     while (n) {
+        pollfd pf{fd, POLLIN, 0};
+        const int pr = ::poll(&pf, 1, timeout_ms);
+        if (pr < 0) {
+            if (errno == EINTR) continue;  // (a signal, e.g. the trace dump's SIGUSR2: keep waiting)
+            g_recv_state = 3;
+            return false;
+        }
+        if (pr == 0) {
+            g_recv_state = 1;
+            return false;
+        }
         ssize_t k = ::recv(fd, p, n, 0);
         if (k < 0) {
             if (errno == EINTR) continue;
+            g_recv_state = 3;
             return false;
         }
-        if (k == 0) return false;
+        if (k == 0) {
+            g_recv_state = 2;
+            return false;
+        }
         p += k;
         n -= (size_t)k;
     }
     return true;
 }
+const char* recv_why() {
+    return g_recv_state == 1   ? "no answer within DFFT_BOOT_TIMEOUT_S (default 180 s): the peer is stuck, or is not in the same collective call"
+           : g_recv_state == 2 ? "the peer closed the connection (it exited, or failed and left the rendezvous)"
+                               : "socket error";
+}
+constexpr uint32_t HELLO_MAGIC = 0x44464654u;  // "DFFT": the listener behind the port really is this job's rank 0
+unsigned long long g_ops = 0;                  // collective operations entered by this process (all ranks count alike)
 
 }  // namespace
 
@@ -134,20 +172,40 @@ int dfft_boot_init(void) {
             fprintf(stderr, "[dfft] rendezvous: rank 0 listening on %s:%d for %d ranks\n", txt, portno, g.size);
         }
         g.peers.assign(g.size, -1);
-        for (int i = 1; i < g.size; ++i) {
+        trace("boot: rank 0 listening", portno, g.size);
+        for (int joined = 1; joined < g.size;) {
+            pollfd pf{ls, POLLIN, 0};
+            const int pr_ = ::poll(&pf, 1, boot_timeout_ms());
+            if (pr_ < 0 && errno == EINTR) continue;
+            if (pr_ <= 0) {
+                ::close(ls);
+                return fail(DFFT_ECOMM, "dfft_boot_init: rank 0 saw only " + std::to_string(joined) + " of " + std::to_string(g.size) +
+                                            " ranks connect within DFFT_BOOT_TIMEOUT_S on port " + std::to_string(portno));
+            }
             int fd = ::accept(ls, nullptr, nullptr);
             if (fd < 0) {
+                if (errno == EINTR || errno == ECONNABORTED) continue;
                 ::close(ls);
-                return fail(DFFT_ECOMM, "dfft_boot_init: accept()");
+                return fail(DFFT_ECOMM, std::string("dfft_boot_init: accept(): ") + strerror(errno));
             }
             setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-            int32_t pr = -1;
-            if (!recv_all(fd, &pr, sizeof(pr)) || pr < 1 || pr >= g.size || g.peers[pr] != -1) {
+            // hello = {magic, rank}; anything else (a port scanner, another job's client that guessed our port) is dropped
+            // without failing the rendezvous
+            uint32_t hello[2] = {0, 0};
+            if (!recv_all(fd, hello, sizeof(hello), 5000) || hello[0] != HELLO_MAGIC || hello[1] < 1 || (int)hello[1] >= g.size ||
+                g.peers[hello[1]] != -1) {
+                trace("boot: dropped a connection that is not a rank of this job", hello[0], hello[1]);
                 ::close(fd);
-                ::close(ls);
-                return fail(DFFT_ECOMM, "dfft_boot_init: bad hello from a peer");
+                continue;
             }
-            g.peers[pr] = fd;
+            const uint32_t ack[2] = {HELLO_MAGIC, (uint32_t)g.size};
+            if (!send_all(fd, ack, sizeof(ack))) {
+                ::close(fd);
+                continue;
+            }
+            g.peers[hello[1]] = fd;
+            trace("boot: rank joined", hello[1], joined);
+            ++joined;
         }
         ::close(ls);
     } else {
@@ -159,20 +217,34 @@ int dfft_boot_init(void) {
         if (getaddrinfo(addr, ps.c_str(), &hints, &res) != 0 || !res)
             return fail(DFFT_ECOMM, std::string("dfft_boot_init: cannot resolve ") + addr);
         int fd = -1;
+        int one = 1;
+        trace("boot: connecting to rank 0", portno, g.rank);
+        int strangers = 0;
         for (int attempt = 0; attempt < 600; ++attempt) {  // rank 0 may start later: retry for ~60 s
             fd = ::socket(AF_INET, SOCK_STREAM, 0);
-            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+            if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
+                // the listener must answer the hello with this job's magic and world size: a port that some OTHER listener
+                // happens to own (torchrun's store is one port below, RCCL's bootstrap sockets take ephemeral ports) accepts
+                // the connection too, and a rank that took it for rank 0 would wait in its first collective for ever
+                setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                const uint32_t hello[2] = {HELLO_MAGIC, (uint32_t)g.rank};
+                uint32_t       ack[2] = {0, 0};
+                if (send_all(fd, hello, sizeof(hello)) && recv_all(fd, ack, sizeof(ack), 10000) && ack[0] == HELLO_MAGIC &&
+                    (int)ack[1] == g.size)
+                    break;
+                ++strangers;
+                trace("boot: the listener on the rendezvous port is not rank 0 of this job", ack[0], ack[1]);
+            }
             if (fd >= 0) ::close(fd);
             fd = -1;
             std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
         freeaddrinfo(res);
-        if (fd < 0) return fail(DFFT_ECOMM, "dfft_boot_init: cannot reach rank 0");
-        int one = 1;
-        setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        int32_t me = g.rank;
-        if (!send_all(fd, &me, sizeof(me))) return fail(DFFT_ECOMM, "dfft_boot_init: hello failed");
+        if (fd < 0)
+            return fail(DFFT_ECOMM, std::string("dfft_boot_init: cannot reach rank 0 at ") + addr + ":" + ps +
+                                        (strangers ? " (a listener that is not this job's rank 0 answered there)" : ""));
         g.hub = fd;
+        trace("boot: joined", g.rank, g.size);
     }
     g.inited = true;
     return DFFT_OK;
@@ -181,23 +253,31 @@ int dfft_boot_init(void) {
 int dfft_boot_rank(void) { return g.rank; }
 int dfft_boot_size(void) { return g.size; }
 
+static int boot_fail(const char* op, int peer) {
+    return fail(DFFT_ECOMM, std::string(op) + " (collective #" + std::to_string(g_ops) + " of rank " + std::to_string(g.rank) + "): waiting for rank " +
+                                std::to_string(peer) + ": " + recv_why());
+}
+
 int dfft_boot_bcast(void* buf, size_t bytes, int root) {
     if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
     if (g.size == 1 || bytes == 0) return DFFT_OK;
+    ++g_ops;
+    trace("boot: bcast enter", (long long)g_ops, root);
     if (root != 0) {  // route through the hub
         if (g.rank == root) {
-            if (!send_all(g.hub, buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send");
+            if (!send_all(g.hub, buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send to rank 0 failed (it has gone)");
         } else if (g.rank == 0) {
-            if (!recv_all(g.peers[root], buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: recv");
+            if (!recv_all(g.peers[root], buf, bytes)) return boot_fail("dfft_boot_bcast", root);
         }
     }
     if (g.rank == 0) {
         for (int i = 1; i < g.size; ++i)
             if (i != root || root == 0)
-                if (!send_all(g.peers[i], buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send");
+                if (!send_all(g.peers[i], buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: send to rank " + std::to_string(i) + " failed (it has gone)");
     } else if (g.rank != root) {
-        if (!recv_all(g.hub, buf, bytes)) return fail(DFFT_ECOMM, "dfft_boot_bcast: recv");
+        if (!recv_all(g.hub, buf, bytes)) return boot_fail("dfft_boot_bcast", 0);
     }
+    trace("boot: bcast done", (long long)g_ops, root);
     return DFFT_OK;
 }
 
@@ -205,18 +285,22 @@ int dfft_boot_allreduce_max(double* v, int n) {
     if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
     if (g.size == 1 || n <= 0) return DFFT_OK;
     const size_t bytes = sizeof(double) * (size_t)n;
+    ++g_ops;
+    trace("boot: allreduce/barrier enter", (long long)g_ops, n);
     if (g.rank == 0) {
         std::vector<double> tmp(n);
         for (int i = 1; i < g.size; ++i) {
-            if (!recv_all(g.peers[i], tmp.data(), bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: recv");
+            if (!recv_all(g.peers[i], tmp.data(), bytes)) return boot_fail("dfft_boot_allreduce_max / barrier", i);
             for (int k = 0; k < n; ++k)
                 if (tmp[k] > v[k]) v[k] = tmp[k];
         }
         for (int i = 1; i < g.size; ++i)
-            if (!send_all(g.peers[i], v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: send");
+            if (!send_all(g.peers[i], v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: send to rank " + std::to_string(i) + " failed (it has gone)");
     } else {
-        if (!send_all(g.hub, v, bytes) || !recv_all(g.hub, v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max");
+        if (!send_all(g.hub, v, bytes)) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: send to rank 0 failed (it has gone)");
+        if (!recv_all(g.hub, v, bytes)) return boot_fail("dfft_boot_allreduce_max / barrier", 0);
     }
+    trace("boot: allreduce/barrier done", (long long)g_ops, n);
     return DFFT_OK;
 }
 

@@ -123,6 +123,7 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
         // collective over all processes: every rank publishes the IPC handle of its receive buffer and maps the others'
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the process rank");
         const int reg = c->next_reg[me]++;
+        trace("comm_register (ipc) enter", reg, c->kind);
         if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
         auto share = [&](void* local, std::vector<void*>& out) -> int {
             hipIpcMemHandle_t mine;
@@ -161,6 +162,7 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
             c->seq[reg] = 0;
         }
         *reg_out = reg;
+        trace("comm_register (ipc) done", reg, c->kind);
     } else {
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the RCCL rank");
         *reg_out = 0;  // receivers post their own ncclRecv: nothing to look up
@@ -176,6 +178,7 @@ int comm_unregister(dfft_comm_t c, int me, int reg) {
     } else if ((c->kind == 2 || c->kind == 3) && reg < (int)c->regs.size()) {
         // collective (plans are destroyed in the same order everywhere): unmap the peers' buffers, and only then may their
         // owners free them
+        trace("comm_unregister (ipc) enter", reg, c->kind);
         for (int q = 0; q < c->P; ++q) {
             void*& r = c->regs[reg][q];
             if (r && q != c->rank) (void)hipIpcCloseMemHandle(r);
@@ -311,6 +314,7 @@ Round part_round(const ExchangeDesc& x, int k, long long cp, int ycut) {
 
 int exchange_local(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStream_t stream) {
     const size_t eb = elem_bytes(x.dtype);
+    trace("exchange (host-synchronised) enter", x.slot, (long long)r.size());
     // every device has finished producing its send buffer and consuming its receive buffer
     DFFT_HIP_TRY(hipStreamSynchronize(stream));
     {
@@ -354,6 +358,7 @@ int exchange_ipc_async(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hip
     if (x.slot < 0 || x.slot >= (int)c->flag_regs.size()) return fail(DFFT_ECOMM, "ipc exchange: plan is not registered");
     const unsigned long long seq = ++c->seq[x.slot];
     const int                P = c->P, me = c->rank;
+    trace("exchange (ipc, stream-ordered) queue round", x.slot, (long long)seq);
     std::vector<char>        is_src(P, 0), is_dst(P, 0);
     for (const Msg& m : r) {
         if (m.peer == me) continue;
@@ -432,6 +437,7 @@ int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStrea
                                         (size_t)m.sc * eb, hipMemcpyDeviceToDevice, stream));
     }
     if (!remote) return DFFT_OK;
+    trace("exchange (rccl) group start", x.me, (long long)r.size());
     ncclResult_t rc = ncclGroupStart();
     if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupStart: ") + ncclGetErrorString(rc));
     // rotation schedule: at distance i send to me+i and receive from me-i (messages of one peer keep their order)
@@ -457,6 +463,7 @@ int exchange_rccl(dfft_comm_t c, const ExchangeDesc& x, const Round& r, hipStrea
         }
     }
     rc = ncclGroupEnd();
+    trace("exchange (rccl) group end", x.me, (long long)rc);
     if (rc != ncclSuccess) return fail(DFFT_ERCCL, std::string("ncclGroupEnd: ") + ncclGetErrorString(rc));
     return DFFT_OK;
 }
@@ -571,7 +578,9 @@ int dfft_comm_create_rccl(const char id[128], int total_devices, int global_idx,
         delete c;
         return fail(DFFT_ENOGPU, "dfft_comm_create_rccl: no HIP device");
     }
+    trace("ncclCommInitRank enter", global_idx, total_devices);
     ncclResult_t r = ncclCommInitRank(&c->nccl, total_devices, u, global_idx);
+    trace("ncclCommInitRank returned", global_idx, (long long)r);
     if (r != ncclSuccess) {
         delete c;
         return fail(DFFT_ERCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
@@ -598,6 +607,7 @@ int dfft_comm_info(dfft_comm_t comm, int* kind, int* size, int* rank, int* devic
 
 int dfft_comm_destroy(dfft_comm_t comm) {
     if (!comm) return DFFT_OK;
+    trace("dfft_comm_destroy", comm->kind, comm->rank);
     if (comm->kind == 1 && comm->nccl) ncclCommDestroy(comm->nccl);
     if (comm->err) (void)hipHostFree(comm->err);
     for (hipStream_t s : comm->peer_streams)

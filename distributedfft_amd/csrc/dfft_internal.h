@@ -11,6 +11,10 @@ namespace dfft {
 
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);
+// control-plane event ring (dfft_trace.cpp): `what` must be a string literal; printed on communication errors, on SIGUSR2
+// (DFFT_TRACE_SIGNAL=1) and by dfft_trace_dump()
+void trace(const char* what, long long a = 0, long long b = 0);
+void trace_on_error(int code, const std::string& msg);
 
 #define DFFT_HIP_TRY(stmt)                                                                                          \
     do {                                                                                                            \

@@ -34,6 +34,7 @@ static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
 int  fail(int code, const std::string& msg) {
     g_last_error = msg;
+    trace_on_error(code, msg);  // communication failures print the process's last control-plane events (dfft_trace.cpp)
     return code;
 }
 
@@ -979,6 +980,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (long_axis && (flags & DFFT_PLAN_NATURAL))
         return fail(DFFT_EUNSUPPORTED, "dfft_plan_create: natural-order plans need single-pass axis lengths (<= 4096)");
     if (long_axis) flags = (flags | DFFT_PLAN_UNFUSED) & ~DFFT_PLAN_OVERLAP;  // the four-step axes run in the reference's stage structure
+    trace("dfft_plan_create", n0 * 1000000 + n1 * 1000 + n2 % 1000, (long long)flags * 100 + total_devices);
     dfft_plan_s* p = new dfft_plan_s;
     p->long_axis = long_axis;
     p->N[0] = n0;
@@ -1327,6 +1329,7 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
         return r;
     };
     const bool zy_used = plan->zy_on;
+    if (plan->P > 1) trace("dfft_execute", plan->direction, exec_flags);
     int        rc = run();
     if (rc) return rc;
     // host-synchronised executes have drained the stream (the reference-named wrapper always executes this way): a one-launch YZ
@@ -1557,7 +1560,9 @@ int dfft_plan_tune_report(dfft_plan_t plan, int max_n, double* ms, int* kept, do
 
 int dfft_plan_sync(dfft_plan_t plan) {
     if (!plan) return fail(DFFT_EINVAL, "dfft_plan_sync: null plan");
+    if (plan->P > 1) trace("dfft_plan_sync enter", plan->direction, plan->flags);
     DFFT_HIP_TRY(hipStreamSynchronize(plan->stream));
+    if (plan->P > 1) trace("dfft_plan_sync stream drained", plan->direction, plan->flags);
     {
         const int rc = zy_check(plan);
         if (rc) return rc;
@@ -1619,6 +1624,7 @@ int dfft_kernel_times(dfft_plan_t plan, double t[3]) {
 
 int dfft_plan_destroy(dfft_plan_t plan) {
     if (!plan) return DFFT_OK;
+    if (plan->P > 1) trace("dfft_plan_destroy", plan->direction, plan->flags);
     if (plan->stream) hipStreamSynchronize(plan->stream);
     if (plan->stream2) hipStreamSynchronize(plan->stream2);
     const int zy_rc = zy_check(plan);  // an execute nobody synchronised through the library: its failure is reported here at the latest

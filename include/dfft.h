@@ -223,6 +223,13 @@ int dfft_boot_bcast(void* buf, size_t bytes, int root);
 int dfft_boot_barrier(void);
 int dfft_boot_allreduce_max(double* v, int n);
 int dfft_boot_finalize(void);
+/* Every wait of the rendezvous is bounded by DFFT_BOOT_TIMEOUT_S (default 180 s, 0 = unbounded): a peer that died or left the
+ * collective call sequence yields DFFT_ECOMM naming the collective, the rank waited for and the reason.
+ * Diagnostics (no counterpart in the reference, whose MPI calls simply hang): the library keeps the last 256 control-plane
+ * events of the process (rendezvous collectives, buffer registrations, exchange rounds, RCCL calls, executes of P > 1 plans).
+ * They are printed to stderr with every DFFT_ECOMM / DFFT_ERCCL failure (DFFT_TRACE_ON_ERROR=0: not), on SIGUSR2 together with
+ * a native backtrace when DFFT_TRACE_SIGNAL=1 is set, and by this call. */
+int dfft_trace_dump(void);
 
 #ifdef __cplusplus
 }
