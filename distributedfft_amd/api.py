@@ -256,9 +256,11 @@ class Plan:
         return list(t)
 
     def destroy(self) -> None:
+        """dfft_plan_destroy.  Its return code is the last place a failure of an execute nobody synchronised THROUGH THE LIBRARY can
+        surface (a caller that waits with torch.cuda.synchronize() instead of sync()): raised here, after the handle is gone."""
         if self.handle:
-            L.load().dfft_plan_destroy(self.handle)
-            self.handle = None
+            h, self.handle = self.handle, None
+            L.check(L.load().dfft_plan_destroy(h), "dfft_plan_destroy")
 
     def __del__(self):
         try:

@@ -12,6 +12,7 @@
 // both sides, and so is any sub-range of its X planes: comm_exchange_part moves planes [k*cp, (k+1)*cp) of every
 // source slab, which lets the plan pipeline t2 behind the plane-chunked t0.
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <cstdlib>
@@ -28,6 +29,8 @@ struct dfft_comm_s {
     std::condition_variable cv;
     int                     arrived = 0;
     unsigned long           generation = 0;
+    int                     agree_in = 0;       // comm_agree_max: the devices' contributions of the round in progress
+    int*                    agree_dev = nullptr;  // rccl: two device words for the one-element all-reduce
     // Receive buffers by registration: every plan registers its receive buffer(s) in creation order, and plans are created
     // in the same order on every device thread / process, so registration r of device q is the buffer device q's r-th
     // exchange descriptor receives into (the reference shares ONE node_data[] between its forward and backward plan and
@@ -109,6 +112,49 @@ int comm_thread_barrier(dfft_comm_t c) {
     return DFFT_OK;
 }
 
+// MAX of `flag` over all devices of the communicator -- how a failure that only ONE device can see (its one-launch YZ stage gave
+// up, dfft_plan.cpp) becomes every device's return code instead of one rank's.  Host-synchronising and collective: called by every
+// device from a host-synchronised execute, after its stream has drained.
+int comm_agree_max(dfft_comm_t c, int me, int flag, hipStream_t stream, int* out) {
+    *out = flag;
+    if (!c || c->P <= 1) return DFFT_OK;
+    trace("comm_agree_max enter", c->kind, flag);
+    if (c->kind == 0) {
+        {
+            std::lock_guard<std::mutex> lk(c->m);
+            if (flag > c->agree_in) c->agree_in = flag;
+        }
+        comm_thread_barrier(c);  // everyone has contributed
+        {
+            std::lock_guard<std::mutex> lk(c->m);
+            *out = c->agree_in;
+        }
+        comm_thread_barrier(c);  // everyone has read
+        if (me == 0) {
+            std::lock_guard<std::mutex> lk(c->m);
+            c->agree_in = 0;
+        }
+        return comm_thread_barrier(c);  // reset before anyone contributes to the next round
+    }
+    if (c->kind == 2 || c->kind == 3) {
+        double v = (double)flag;
+        const int rc = dfft_boot_allreduce_max(&v, 1);
+        if (rc) return rc;
+        *out = (int)v;
+        return DFFT_OK;
+    }
+    // rccl: one-element all-reduce on the plan's stream
+    if (!c->agree_dev) DFFT_HIP_TRY(hipMalloc((void**)&c->agree_dev, 2 * sizeof(int)));
+    DFFT_HIP_TRY(hipMemcpyAsync(c->agree_dev, &flag, sizeof(int), hipMemcpyHostToDevice, stream));
+    ncclResult_t r = ncclAllReduce(c->agree_dev, c->agree_dev + 1, 1, ncclInt, ncclMax, c->nccl, stream);
+    if (r != ncclSuccess) return fail(DFFT_ERCCL, std::string("comm_agree_max: ncclAllReduce: ") + ncclGetErrorString(r));
+    int got = flag;
+    DFFT_HIP_TRY(hipMemcpyAsync(&got, c->agree_dev + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DFFT_HIP_TRY(hipStreamSynchronize(stream));
+    *out = got;
+    return DFFT_OK;
+}
+
 int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out) {
     if (me < 0 || me >= c->P || !reg_out) return fail(DFFT_EINVAL, "comm_register: index out of range");
     *reg_out = -1;
@@ -126,8 +172,25 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
         trace("comm_register (ipc) enter", reg, c->kind);
         if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
         auto share = [&](void* local, std::vector<void*>& out) -> int {
+            // hipIpcGetMemHandle was seen failing with "invalid argument" once in 20 four-process launches on one GPU (round 5,
+            // tools/stall_hunt.py iteration 13: the second pair of plans of a process, i.e. freshly recycled memory, with
+            // HSA_ENABLE_IPC_MODE_LEGACY=0) -- transient on the runtime's side: a few spaced attempts before the error is final.
+            // Every rank still takes part in the broadcasts below either way, so a rank that fails here fails ALONE and its peers
+            // learn of it from the rendezvous (closed connection) instead of waiting for a handle that never comes.
             hipIpcMemHandle_t mine;
-            DFFT_HIP_TRY(hipIpcGetMemHandle(&mine, local));
+            hipError_t        ge = hipErrorUnknown;
+            for (int attempt = 0; attempt < 5 && ge != hipSuccess; ++attempt) {
+                if (attempt) {
+                    (void)hipGetLastError();
+                    trace("hipIpcGetMemHandle failed, trying again", attempt, (long long)ge);
+                    (void)hipDeviceSynchronize();
+                    usleep(2000u << attempt);
+                }
+                ge = hipIpcGetMemHandle(&mine, local);
+            }
+            if (ge != hipSuccess)
+                return fail(DFFT_EHIP, std::string("hipIpcGetMemHandle failed five times: ") + hipGetErrorString(ge) +
+                                           " (is HSA_ENABLE_IPC_MODE_LEGACY=0 set, as this driver needs?)");
             for (int q = 0; q < c->P; ++q) {
                 hipIpcMemHandle_t h = mine;
                 int               rc = dfft_boot_bcast(&h, sizeof(h), q);
@@ -610,6 +673,7 @@ int dfft_comm_destroy(dfft_comm_t comm) {
     trace("dfft_comm_destroy", comm->kind, comm->rank);
     if (comm->kind == 1 && comm->nccl) ncclCommDestroy(comm->nccl);
     if (comm->err) (void)hipHostFree(comm->err);
+    if (comm->agree_dev) (void)hipFree(comm->agree_dev);
     for (hipStream_t s : comm->peer_streams)
         if (s) {
             (void)hipStreamSynchronize(s);

@@ -93,6 +93,8 @@ int comm_exchange_part(dfft_comm_t comm, const ExchangeDesc& x, int k, long long
 // The messages comm_exchange_part issues (same order), for inspection through the C-ABI (dfft_exchange_part_layout).
 void comm_part_messages(const ExchangeDesc& x, int k, long long cp, int ycut, std::vector<int>& peer, std::vector<long long>& so,
                         std::vector<long long>& sc, std::vector<long long>& ro, std::vector<long long>& rc);
+// MAX of `flag` over all devices (host-synchronising, collective): turns a failure only one device can see into every device's.
+int comm_agree_max(dfft_comm_t comm, int me, int flag, hipStream_t stream, int* out);
 // Thread barrier over the P local device-threads (no-op for RCCL communicators).
 int comm_thread_barrier(dfft_comm_t comm);
 

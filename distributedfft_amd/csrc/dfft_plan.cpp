@@ -104,7 +104,9 @@ static AxisMap plain_axis(long long n, long long stride, long long cstride) {
     return m;
 }
 
-// experiment knobs: DFFT_Z_GRID / DFFT_Y_GRID / DFFT_X_GRID cap the persistent grid of the respective pass
+// experiment knobs: DFFT_Z_GRID / DFFT_Y_GRID / DFFT_X_GRID cap the persistent grid of the respective pass -- a tuning knob and the
+// tests' way to give a workgroup many tiles.  Read ONCE per plan (dfft_plan_create), never on the launch path: getenv is not safe
+// against a concurrent setenv of another device thread.
 static int env_grid(const char* name) {
     const char* e = getenv(name);
     return e ? atoi(e) : 0;
@@ -124,11 +126,12 @@ struct SlabLayout {
 
 // scratch slab of the plan that is executing on this thread (long-axis plans; set by dfft_execute)
 static thread_local void* t_plan_scratch = nullptr;
+static thread_local int   t_plan_zgrid = 0;  // the executing plan's cap on its row launches' grids (dfft_plan_s::grid_z)
 
 // contiguous rows: `rows` FFTs of length n; row pitch n, or (lin/lout given) rows_per_plane rows per plane in the given layouts
 static int fft_rows(const void* in, void* out, int n, long long rows, int dtype, int dir, hipStream_t s,
                     long long first_row = 0, int hints = 0, double scale = 1.0, const SlabLayout* lin = nullptr,
-                    const SlabLayout* lout = nullptr, long long rows_per_plane = 0, void* long_scratch_buf = nullptr) {
+                    const SlabLayout* lout = nullptr, long long rows_per_plane = 0, void* long_scratch_buf = nullptr, int grid_limit = 0) {
     if (n > 4096) {  // beyond the single-pass range: four-step decomposition (dfft_long.hip), plain contiguous rows only
         if (lin || lout) return fail(DFFT_EINVAL, "fft_rows: long axes use the natural layout");
         if (rows <= 0) return DFFT_OK;
@@ -169,8 +172,7 @@ static int fft_rows(const void* in, void* out, int n, long long rows, int dtype,
         L.tiles_per_a = (int)rows_per_plane;
         L.a_first = first_row / rows_per_plane;
     }
-    const int zgrid = env_grid("DFFT_Z_GRID");  // (read per launch: a tuning knob and the tests' way to give a workgroup many tiles)
-    L.grid_limit = zgrid;
+    L.grid_limit = grid_limit ? grid_limit : t_plan_zgrid;  // (dfft_plan_s::grid_z: DFFT_Z_GRID when the plan was created)
     return check_launch(launch_fft(L, s), "fft_rows");
 }
 
@@ -239,6 +241,7 @@ struct dfft_plan_s {
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
     bool                    zy_lazy = false;           // lazy-publish form of the one-launch kernel (un-packed launches; DFFT_ZY_LAZY=0: eager)
     int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
+    int                     grid_x = 0, grid_y = 0, grid_z = 0;  // DFFT_X_GRID / DFFT_Y_GRID / DFFT_Z_GRID when the plan was created (0 = no cap)
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
     // received planes are a power-of-two distance apart.  0 = off.
     int                     rot_elems = 0;
@@ -355,8 +358,7 @@ static int launch_y(dfft_plan_s* p, const void* in, void* out, bool packed_side_
         L.rot.a0 = (int)p->sx.start(p->me);
         (packed_side_is_out ? L.rot.out_mode : L.rot.in_mode) = 1;
     }
-    const int ygrid = env_grid("DFFT_Y_GRID");
-    L.grid_limit = ygrid;
+    L.grid_limit = p->grid_y;
     return check_launch(launch_fft(L, p->stream), "Y pass");
 }
 
@@ -407,8 +409,7 @@ static int launch_x(dfft_plan_s* p, const void* in, void* out, bool keep_slab = 
         L.rot.mask = (int)n2 - 1;
         (p->direction == DFFT_FORWARD ? L.rot.in_mode : L.rot.out_mode) = 2;
     }
-    const int xgrid = env_grid("DFFT_X_GRID");
-    L.grid_limit = xgrid;
+    L.grid_limit = p->grid_x;
     L.hints |= p->x_hints;
     return check_launch(launch_fft(L, p->stream), "X pass");
 }
@@ -1001,6 +1002,9 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     p->xs = p->sx.size(global_idx);
     p->ys = p->sy.size(global_idx);
     p->comm = comm;
+    p->grid_x = env_grid("DFFT_X_GRID");
+    p->grid_y = env_grid("DFFT_Y_GRID");
+    p->grid_z = env_grid("DFFT_Z_GRID");
     p->host_timed = false;
     for (double& t : p->host_t) t = 0;
     if (p->sx.size(total_devices - 1) < 1 || p->sy.size(total_devices - 1) < 1) {
@@ -1044,8 +1048,15 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         }
     }
     if (e == hipSuccess) e = hipMalloc(&p->buf1, bytes);
-    if (e == hipSuccess) e = hipMemcpy(p->buf1, in, bytes, hipMemcpyDeviceToDevice);  // :77 input captured at plan time
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    // :77 input captured at plan time.  A device-to-device hipMemcpy on the null stream may return before the copy has run and is not
+    // ordered with this plan's (non-blocking) stream -- and bufferDev1 is the RECEIVE buffer of the exchange: a copy that ran late
+    // would overwrite data a peer had pushed already (round 5, tools/stall_hunt.py: the overlapped backward plan's first batch
+    // differed from the serial result in 2 of 20 four-process runs).  So: everything the caller queued (whatever stream produced
+    // `in`) is waited for, the copy runs on the plan's own stream, and plan creation returns when it has landed.
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyAsync(p->buf1, in, bytes, hipMemcpyDeviceToDevice, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
     for (auto& ev : p->ev)
         if (e == hipSuccess) e = hipEventCreate(&ev);
     // forward: always; backward: out-of-place plans that read the caller's `in` (the inverse X pass of sub-block k+1 must
@@ -1315,17 +1326,20 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     plan->timed = sync || !(exec_flags & DFFT_EXEC_NO_TIMING);
     if (!plan->timed && (exec_flags & DFFT_EXEC_PRINT)) return fail(DFFT_EINVAL, "dfft_execute: PRINT needs stage timing");
     // an earlier execute of the one-launch YZ stage that gave up and that nobody synchronised through the library (the pinned error
-    // word is readable at any time): report it before anything else is queued; the stage is off from here on
-    {
-        const int zrc = zy_check(plan);
-        if (zrc) return zrc;
-    }
+    // word is readable at any time): report it before anything else is queued; the stage is off from here on.  A plan with an
+    // exchange queues this execute all the same (on the two-launch stage) and reports afterwards: returning early on ONE rank would
+    // leave its peers waiting in the exchange for a partner that never comes.
+    const int   zrc0 = zy_check(plan);
+    std::string zmsg0 = zrc0 ? g_last_error : std::string();
+    if (zrc0 && !plan->exch) return zrc0;
     auto run = [&]() {
         t_plan_scratch = plan->lbuf;
+        t_plan_zgrid = plan->grid_z;
         const int r = (plan->flags & DFFT_PLAN_NATURAL) ? execute_natural(plan, sync)
                       : plan->direction == DFFT_FORWARD ? execute_forward(plan, sync)
                                                         : execute_backward(plan, sync);
         t_plan_scratch = nullptr;
+        t_plan_zgrid = 0;
         return r;
     };
     const bool zy_used = plan->zy_on;
@@ -1336,7 +1350,26 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     // stage that gave up is seen here, before any timing is printed or any result used.  Where the pipeline has not written its own
     // input -- fused single-GPU plans that read `in` or bufferDev1 and work in the hand-over buffer -- the transform is simply run
     // again on two launches per chunk (zy_check has switched the stage off); otherwise the failure is the return code.
-    if (sync && zy_used) {
+    if (sync && plan->exch && plan->zy_ctl) {
+        // P > 1: the failure is rank-local knowledge, but the exchange has already shipped this rank's invalid data to every peer.
+        // Every device of the communicator learns of it here (every plan of the communicator that was BUILT with the stage takes
+        // part, whether its own stage is still on or not -- the condition must not depend on a rank's own history), returns an error
+        // and continues on the two-launch stage, so no rank ever returns DFFT_OK for an execute that any rank knows to be invalid.
+        int mine = zrc0 ? 1 : 0;
+        if (!mine && zy_used) {
+            mine = zy_check(plan) ? 1 : 0;
+            if (mine) zmsg0 = g_last_error;
+        }
+        int any = 0;
+        rc = comm_agree_max(plan->comm, plan->me, mine, plan->stream, &any);
+        if (rc) return rc;
+        if (any) {
+            plan->zy_on = false;
+            return mine ? fail(DFFT_EHIP, zmsg0)
+                        : fail(DFFT_EHIP, "the one-launch YZ stage gave up on another device of this communicator: the results of this execute are invalid on "
+                                          "every device; later executes use the two-launch stage");
+        }
+    } else if (sync && zy_used) {
         rc = zy_check(plan);
         if (rc) {
             const void* src = (plan->flags & DFFT_PLAN_INPUT_FROM_IN) ? plan->in : plan->buf1;
@@ -1347,6 +1380,7 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
             if (rc) return rc;
         }
     }
+    if (zrc0) return fail(zrc0, zmsg0);  // (asynchronous execute of a P > 1 plan: queued for the peers' sake, invalid all the same)
     // host-synchronised executes have drained the stream: an asynchronous exchange that timed out on a dead or slow peer
     // must not let the caller print timings / use results (the reference-named wrapper always executes this way)
     if (sync && plan->comm) {

@@ -383,10 +383,14 @@ def test_one_launch_t0_failure_is_loud_and_recovered(gpu, direction, monkeypatch
     # (b) asynchronous executes: the failure surfaces at the next synchronisation through the library
     monkeypatch.setenv("DFFT_ZY_FAULT", "1")
     p = api.Plan(*N, a, b, None, 0, 1, direction, api.PLAN_INPUT_FROM_IN)
-    for _ in range(3):                        # the first launch fails, two more are queued behind it
-        p.execute(api.EXEC_NO_TIMING)
+    # the first launch fails, two more are queued behind it.  dfft_execute looks at the pinned error word on entry, and with so
+    # few polls the failing kernel gives up within milliseconds: on a slow host the second or third execute call may already
+    # report the failure -- wherever it surfaces, it must be the same loud error, once
     with pytest.raises(DfftError, match="one-launch YZ stage gave up"):
+        for _ in range(3):
+            p.execute(api.EXEC_NO_TIMING)
         p.sync()
+    p.sync()                                  # (drains whatever was queued before the report; nothing new to report)
     assert "yz_stage=two-launches-per-chunk" in p.describe()
     b.zero_()
     p.execute(api.EXEC_NO_TIMING)
@@ -404,6 +408,74 @@ def test_one_launch_t0_failure_is_loud_and_recovered(gpu, direction, monkeypatch
     p.sync()
     assert torch.equal(b, good)
     p.destroy()
+
+
+def test_one_launch_t0_failure_is_collective(gpu, monkeypatch):
+    """P > 1: the one-launch YZ stage of ONE device gives up.  Its garbage has gone through the exchange by the time the
+    host sees the error word, so every device must return the error from that host-synchronised execute -- not only the one whose
+    stage failed -- and all of them continue on two launches per chunk with correct results.  An asynchronous execute on the
+    failing device still queues its exchange (its peers must not be left waiting) and reports afterwards."""
+    import torch
+    from distributedfft_amd import api
+    from distributedfft_amd._lib import DfftError
+    N, P = (8, 512, 512), 2
+    n0, n1, n2 = N
+    x = so.random_input(N, seed=77)
+    ref = so.fftn_reference(x, P)
+    scale = max(np.abs(r).max() for r in ref)
+    monkeypatch.setenv("DFFT_ZY_SPIN_POLLS", "2000")
+    for first_exec in (api.EXEC_SYNC_STAGES, api.EXEC_NO_TIMING):
+        comm = api.Comm.local(P)
+        plans, outs = [], []
+        for g in range(P):
+            mc = api.get_max_data_count(n0, n1, n2, P, g == P - 1)
+            a = torch.zeros(mc, dtype=torch.complex128, device=gpu)
+            b = torch.zeros(mc, dtype=torch.complex128, device=gpu)
+            src = torch.from_numpy(np.ascontiguousarray(x[g * (n0 // P):(g + 1) * (n0 // P)]).reshape(-1)).to(gpu)
+            a[:src.numel()] = src
+            torch.cuda.synchronize()
+            if g == 1:
+                monkeypatch.setenv("DFFT_ZY_FAULT", "1")   # only this device's first launch of the stage fails
+            plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, api.FORWARD, api.PLAN_INPUT_FROM_IN))
+            monkeypatch.delenv("DFFT_ZY_FAULT", raising=False)
+            assert "yz_stage=one-launch" in plans[-1].describe()
+            outs.append((a, b))
+        seen = [None] * P
+
+        def work(g):
+            try:
+                plans[g].execute(first_exec)
+                if first_exec == api.EXEC_NO_TIMING:      # asynchronous: the failing device reports at its next sync / execute
+                    plans[g].sync()
+            except DfftError as e:
+                seen[g] = str(e)
+
+        th = [threading.Thread(target=work, args=(g,)) for g in range(P)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert seen[1] and "one-launch YZ stage gave up" in seen[1], seen
+        if first_exec == api.EXEC_SYNC_STAGES:             # host-synchronised: every device knows
+            assert seen[0] and "one-launch YZ stage gave up" in seen[0], seen
+            assert all("yz_stage=two-launches-per-chunk" in p.describe() for p in plans)
+        seen = [None] * P
+        first_exec_again = api.EXEC_SYNC_STAGES
+
+        def again(g):
+            try:
+                plans[g].execute(first_exec_again)
+            except DfftError as e:
+                seen[g] = str(e)
+
+        th = [threading.Thread(target=again, args=(g,)) for g in range(P)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert seen == [None] * P, seen
+        for g in range(P):
+            got = outs[g][1].cpu().numpy()[:ref[g].size].reshape(ref[g].shape)
+            assert np.abs(got - ref[g]).max() / scale < 1e-11, g
+        for p in plans:
+            p.destroy()
+        comm.destroy()
 
 
 @pytest.mark.parametrize("rot", ["0", "1"])
