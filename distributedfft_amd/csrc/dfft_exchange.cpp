@@ -17,7 +17,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <string>
 
 #include "dfft_internal.h"
 
@@ -31,6 +33,18 @@ struct dfft_comm_s {
     unsigned long           generation = 0;
     int                     agree_in = 0;       // comm_agree_max: the devices' contributions of the round in progress
     int*                    agree_dev = nullptr;  // rccl: two device words for the one-element all-reduce
+    // IPC communicators: receive buffers and their registrations (the peers' mappings, the flag words) are kept for the life of the
+    // communicator and handed to the next plan that asks with the same key (comm_recv_alloc) -- see there for why
+    struct PoolEntry {
+        std::string key;
+        void*       buf;
+        size_t      bytes;
+        int         reg;
+        bool        used;
+    };
+    std::vector<PoolEntry>       pool;
+    std::map<void*, std::string> pending;  // fresh allocations of comm_recv_alloc that are not registered yet
+    bool                         pooled = false;
     // Receive buffers by registration: every plan registers its receive buffer(s) in creation order, and plans are created
     // in the same order on every device thread / process, so registration r of device q is the buffer device q's r-th
     // exchange descriptor receives into (the reference shares ONE node_data[] between its forward and backward plan and
@@ -112,6 +126,47 @@ int comm_thread_barrier(dfft_comm_t c) {
     return DFFT_OK;
 }
 
+// Receive buffers of IPC communicators are POOLED (round 5).  Exporting a buffer to the peers (hipIpcGetMemHandle / OpenMemHandle),
+// closing the mappings, freeing it and exporting the next allocation -- which the driver places on the just-freed memory -- is
+// what a second generation of plans on one communicator does, and on this stack (ROCm 7, dmabuf IPC) it is not reliable:
+// in tools/stall_hunt.py's four-process runs the second generation failed in 7 of 80 launches -- hipIpcGetMemHandle returning
+// "invalid argument" (also when repeated), or, silently, a peer's fresh mapping still pointing at the memory of the buffer that
+// had been there before, so that everything that peer pushed was lost and the plan's results were wrong for as long as it lived
+// (profiles/r05/README.md section 1).  So a registered buffer is never unmapped or freed while its communicator lives: a plan that
+// is destroyed hands buffer + registration back, and the next plan that asks with the same key (size, precision, device count,
+// role) gets them -- no handle is created twice for one piece of memory, and re-planning costs no rendezvous round trips.  Plans
+// are created and destroyed in the same order on every rank, so every rank makes the same choice.  DFFT_IPC_POOL=0 restores the
+// export / unmap / free cycle per plan (A/B switch).
+int comm_recv_alloc(dfft_comm_t c, const std::string& key, size_t bytes, void** out) {
+    *out = nullptr;
+    if (c && c->pooled) {
+        for (auto& e : c->pool) {
+            if (e.used || e.key != key) continue;
+            if (e.bytes < bytes) return fail(DFFT_ECOMM, "comm_recv_alloc: pooled buffer '" + key + "' is smaller than requested");
+            e.used = true;
+            *out = e.buf;
+            trace("comm_recv_alloc: pooled buffer reused", e.reg, (long long)bytes);
+            return DFFT_OK;
+        }
+    }
+    DFFT_HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    if (c && c->pooled) c->pending[*out] = key + "#" + std::to_string(bytes);
+    return DFFT_OK;
+}
+int comm_recv_free(dfft_comm_t c, void* buf) {
+    if (!buf) return DFFT_OK;
+    if (c && c->pooled) {
+        for (auto& e : c->pool)
+            if (e.buf == buf) {
+                e.used = false;  // stays allocated, exported and mapped by the peers
+                return DFFT_OK;
+            }
+        c->pending.erase(buf);
+    }
+    DFFT_HIP_TRY(hipFree(buf));
+    return DFFT_OK;
+}
+
 // MAX of `flag` over all devices of the communicator -- how a failure that only ONE device can see (its one-launch YZ stage gave
 // up, dfft_plan.cpp) becomes every device's return code instead of one rank's.  Host-synchronising and collective: called by every
 // device from a host-synchronised execute, after its stream has drained.
@@ -168,6 +223,11 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
     } else if (c->kind == 2 || c->kind == 3) {
         // collective over all processes: every rank publishes the IPC handle of its receive buffer and maps the others'
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the process rank");
+        for (const auto& e : c->pool)
+            if (e.buf == recvbuf) {  // a pooled buffer: registered (and mapped by every peer) since its first plan
+                *reg_out = e.reg;
+                return DFFT_OK;
+            }
         const int reg = c->next_reg[me]++;
         trace("comm_register (ipc) enter", reg, c->kind);
         if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
@@ -225,6 +285,15 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
             c->seq[reg] = 0;
         }
         *reg_out = reg;
+        if (c->pooled) {
+            auto it = c->pending.find(recvbuf);
+            if (it != c->pending.end()) {
+                const size_t      cut = it->second.rfind('#');
+                dfft_comm_s::PoolEntry pe{it->second.substr(0, cut), recvbuf, (size_t)std::stoull(it->second.substr(cut + 1)), reg, true};
+                c->pool.push_back(pe);
+                c->pending.erase(it);
+            }
+        }
         trace("comm_register (ipc) done", reg, c->kind);
     } else {
         if (me != c->rank) return fail(DFFT_EINVAL, "comm_register: plan index does not match the RCCL rank");
@@ -239,6 +308,8 @@ int comm_unregister(dfft_comm_t c, int me, int reg) {
         std::lock_guard<std::mutex> lk(c->m);
         if (reg < (int)c->regs.size()) c->regs[reg][me] = nullptr;
     } else if ((c->kind == 2 || c->kind == 3) && reg < (int)c->regs.size()) {
+        for (const auto& e : c->pool)
+            if (e.reg == reg) return DFFT_OK;  // pooled: the registration outlives the plan (comm_recv_free hands it back)
         // collective (plans are destroyed in the same order everywhere): unmap the peers' buffers, and only then may their
         // owners free them
         trace("comm_unregister (ipc) enter", reg, c->kind);
@@ -600,6 +671,10 @@ int dfft_comm_create_ipc(int total_devices, int global_idx, int async_exchange, 
     c->kind = async_exchange ? 3 : 2;
     c->P = total_devices;
     c->rank = global_idx;
+    {
+        const char* pe = getenv("DFFT_IPC_POOL");
+        c->pooled = !(pe && *pe == '0');
+    }
     c->next_reg.assign(total_devices, 0);
     c->devices.assign(total_devices, -1);
     if (hipGetDevice(&c->device) != hipSuccess) {
@@ -672,6 +747,25 @@ int dfft_comm_destroy(dfft_comm_t comm) {
     if (!comm) return DFFT_OK;
     trace("dfft_comm_destroy", comm->kind, comm->rank);
     if (comm->kind == 1 && comm->nccl) ncclCommDestroy(comm->nccl);
+    if (!comm->pool.empty()) {
+        // pooled registrations: unmap the peers' buffers and flag words, meet the peers (best effort: a rank that has died must not
+        // keep the others from leaving), then free this rank's own
+        (void)hipDeviceSynchronize();
+        for (const auto& e : comm->pool) {
+            for (int q = 0; q < comm->P; ++q) {
+                if (q == comm->rank) continue;
+                if (e.reg < (int)comm->regs.size() && comm->regs[e.reg][q]) (void)hipIpcCloseMemHandle(comm->regs[e.reg][q]);
+                if (e.reg < (int)comm->flag_regs.size() && comm->flag_regs[e.reg][q]) (void)hipIpcCloseMemHandle(comm->flag_regs[e.reg][q]);
+            }
+        }
+        (void)hipGetLastError();
+        (void)dfft_boot_barrier();
+        for (const auto& e : comm->pool) {
+            if (e.reg < (int)comm->flag_regs.size() && comm->flag_regs[e.reg][comm->rank]) (void)hipFree(comm->flag_regs[e.reg][comm->rank]);
+            (void)hipFree(e.buf);
+        }
+        comm->pool.clear();
+    }
     if (comm->err) (void)hipHostFree(comm->err);
     if (comm->agree_dev) (void)hipFree(comm->agree_dev);
     for (hipStream_t s : comm->peer_streams)

@@ -80,6 +80,11 @@ inline void part_range(long long xs_g, long long cp, int k, long long* x0, long 
 // the same order on every device thread / process; the IPC communicator makes this call collective.
 int comm_register(dfft_comm_t comm, int me, void* recvbuf, int device, int* reg);
 int comm_unregister(dfft_comm_t comm, int me, int reg);
+// Device memory for a buffer that a plan is going to register as a receive buffer (`key`: everything that determines its size
+// and role, identical on every rank), and its release.  IPC communicators keep such buffers and their registrations for their
+// whole life and reuse them (dfft_exchange.cpp, comm_recv_alloc); everywhere else these are hipMalloc / hipFree.
+int comm_recv_alloc(dfft_comm_t comm, const std::string& key, size_t bytes, void** out);
+int comm_recv_free(dfft_comm_t comm, void* buf);
 int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl, 2 ipc (host-synchronised), 3 ipc (stream-ordered)
 bool comm_is_async(dfft_comm_t comm);  // exchanges are enqueued on the stream (rccl, ipc-async) instead of blocking the host
 int comm_check(dfft_comm_t comm);      // error reported by an asynchronous exchange since the last check

@@ -1047,7 +1047,10 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
             }
         }
     }
-    if (e == hipSuccess) e = hipMalloc(&p->buf1, bytes);
+    // buffers that are (or may be) registered as receive buffers come from the communicator (pooled per key by IPC communicators)
+    const std::string rkey = std::to_string(n0) + "x" + std::to_string(n1) + "x" + std::to_string(n2) + ":" + std::to_string(dtype) + ":" +
+                             std::to_string(total_devices);
+    if (e == hipSuccess && comm_recv_alloc(comm, rkey + ":b1", bytes, &p->buf1) != DFFT_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     // :77 input captured at plan time.  A device-to-device hipMemcpy on the null stream may return before the copy has run and is not
     // ordered with this plan's (non-blocking) stream -- and bufferDev1 is the RECEIVE buffer of the exchange: a copy that ran late
@@ -1065,11 +1068,16 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         (direction == DFFT_FORWARD || (flags & DFFT_PLAN_INPUT_FROM_IN))) {
         // parts: DFFT_OVERLAP_PARTS (default 4) per slab, never larger than one Infinity-Cache chunk; derived from the
         // global block size ceil(N0/P) so that every rank cuts identically
-        long long   parts = 4;
-        const char* pe = getenv("DFFT_OVERLAP_PARTS");
+        // How many: every part is a launch of its own (the one-launch YZ stage or a Z + Y pair) plus an exchange round, and short
+        // launches pay their ramps -- four parts at every P taxed the local work of 512^3 fp64 by 30-40 % at P = 8, where a part was
+        // 16 planes = 64 MiB = 40 us of work (t0 0.156 -> 0.207 ms per rank, profiles/r04/local_by_P.log), a third of what the overlap
+        // can hide there.  So parts are sized, not counted: at least 128 MiB of slab each, between 2 and 4 of them (P = 8: 2 parts of
+        // 128 MiB, P = 4 and below: 4), then capped by the cache chunk as before.  DFFT_OVERLAP_PARTS=n overrides.
+        const long long plane_bytes = n1 * n2 * (long long)elem_bytes(dtype);
+        long long       parts = std::min(4ll, std::max(2ll, (p->sx.blk * plane_bytes + (128ll << 20) - 1) / (128ll << 20)));
+        const char*     pe = getenv("DFFT_OVERLAP_PARTS");
         if (pe && atoll(pe) > 0) parts = atoll(pe);
         long long pp = (p->sx.blk + parts - 1) / parts;
-        const long long plane_bytes = n1 * n2 * (long long)elem_bytes(dtype);
         const long long cache_planes = std::max(1ll, (256ll << 20) / plane_bytes);
         if (pp > cache_planes) pp = cache_planes;
         if (pp < 1) pp = 1;
@@ -1103,10 +1111,9 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (natural && p->exch) {
         // natural-order plans re-slab twice (X->Y for the X pass, Y->X to return to the caller's layout); the second
         // exchange receives the packed [src][xs][yl_src][N2] blocks into a buffer of its own and uses the other slot
-        e = hipMalloc(&p->rbuf, bytes);
-        if (e != hipSuccess) {
+        if (comm_recv_alloc(comm, rkey + ":nat", bytes, &p->rbuf) != DFFT_OK) {
             dfft_plan_destroy(p);
-            return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+            return fail(DFFT_EHIP, "dfft_plan_create: no memory for the second receive buffer");
         }
         fill_exchange(p, p->xd2, DFFT_BACKWARD);
         p->xd2.sendbuf = p->buf2;
@@ -1120,10 +1127,9 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (p->part_planes > 0) {
         // overlap mode: parts arrive while later planes are still being transformed in bufferDev1, so the exchange
         // needs a receive buffer of its own (one more slab in HBM; 288 GB makes that a non-issue)
-        e = hipMalloc(&p->rbuf, bytes);
-        if (e != hipSuccess) {
+        if (comm_recv_alloc(comm, rkey + ":rb", bytes, &p->rbuf) != DFFT_OK) {
             dfft_plan_destroy(p);
-            return fail(DFFT_EHIP, std::string("dfft_plan_create: ") + hipGetErrorString(e));
+            return fail(DFFT_EHIP, "dfft_plan_create: no memory for the receive buffer of the overlapped exchange");
         }
         if (direction == DFFT_FORWARD) p->xd.recvbuf = p->rbuf;  // Y pass -> out (send) -> rbuf (receive) -> X pass -> out
         else p->xd.sendbuf = p->rbuf;                            // in -> X pass -> rbuf (send) -> bufferDev1 -> Y,Z -> out
@@ -1675,8 +1681,8 @@ int dfft_plan_destroy(dfft_plan_t plan) {
         if (e) hipEventDestroy(e);
     if (plan->stream2) hipStreamDestroy(plan->stream2);
     if (plan->stream) hipStreamDestroy(plan->stream);
-    if (plan->buf1) hipFree(plan->buf1);
-    if (plan->rbuf) hipFree(plan->rbuf);
+    (void)comm_recv_free(plan->comm, plan->buf1);
+    (void)comm_recv_free(plan->comm, plan->rbuf);
     if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
     if (plan->zy_ctl) hipFree(plan->zy_ctl);

@@ -26,20 +26,14 @@ def _free_port():
     return p
 
 
-def _launch(world, argv, extra_env=None, timeout=300, expect_rc=0, retries=1):
-    """_launch_once, repeated once when the LAUNCH failed (a rank did not finish or exited with an unexpected code): several
-    processes on one GPU -- and RCCL driven into its duplicate-device error on purpose -- is this file's own artefact, and twice in
-    round 4 a case that takes seconds stalled for minutes and failed, then passed when repeated (profiles/r04/README.md section 6).
-    What the ranks had printed goes into a warning; assertions on RESULTS are made by the callers on the output of the run that
-    finished and are never retried."""
-    for attempt in range(retries + 1):
-        try:
-            return _launch_once(world, argv, extra_env, timeout, expect_rc)
-        except AssertionError as e:
-            if attempt == retries:
-                raise
-            import warnings
-            warnings.warn(f"multi-process launch failed (attempt {attempt + 1}), repeating it:\n" + str(e)[-3000:])
+def _launch(world, argv, extra_env=None, timeout=300, expect_rc=0):
+    """One attempt, no retry.  Round 4 repeated a failed launch once because two cases had "stalled for minutes and passed when
+    repeated"; round 5 found what that was (profiles/r05/README.md section 1): not a stall but a WRONG RESULT on one rank -- a
+    second generation of plans on one IPC communicator whose re-exported receive buffer a peer had mapped onto stale memory, or
+    whose plan-time input copy ran late on the null stream -- after which the rank's assertion killed it and its peers waited for
+    it in the next exchange.  Both causes are fixed in the library (pooled registrations, plan-time copy on the plan's stream), the
+    rendezvous' waits are bounded, and a launch that fails is a finding again."""
+    return _launch_once(world, argv, extra_env, timeout, expect_rc)
 
 
 def _launch_once(world, argv, extra_env=None, timeout=300, expect_rc=0):
