@@ -1204,8 +1204,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         const long long ysub = p->sy.blk / std::max(1, p->ycuts);
         const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2 || DFFT_ZY_ROW_PITCH);
-        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % (n1 / 8) == 0;  // even splits; a
-                                   // destination block is a whole number of the column unit's 8-point-per-thread strides
+        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % zy_col_threads((int)n1) == 0;  // even splits; a
+                                   // destination block is a whole number of the column unit's strides (the threads of one column FFT)
         // Where the stage is used by itself (DFFT_T0_ONE_LAUNCH=0: never; =1: wherever the kernel exists on single-GPU plans; =all:
         // P > 1 plans too).  Round 3 used it for 512 x 512-point planes on a single GPU only; since round 4
         //  * un-packed launches with a 256-point Y axis take column tiles of two cache lines (ZyTile, dfft_zy.hip: 512-thread
@@ -1217,7 +1217,9 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         //    eagerly): per rank at 512^3 fp64, exchange switched off, t0 / back-to-back P = 2 0.690 / 1.052 -> 0.630 / 0.94, P = 4
         //    0.343 / 0.512 -> 0.32 / 0.492, P = 8 0.174 / 0.255 -> 0.157 / 0.248 (experiments/lib_ab_lazy_packed.log) -- used by itself
         //    for 512 x 512-point planes (packed tiles stay one line wide, so planes with a 256-point axis keep two launches).
-        const bool      multi_on = (n1 == 512 && n2 == 512) || (oe && !strcmp(oe, "all"));
+        //  * round 5: planes with a 768-point Y axis (BASELINE config 4: 768 x 512; 24 points per thread, 256-thread units, the twiddle
+        //    table of the Y axis in LDS like the two-launch kernel's), single-GPU and packed.
+        const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512) || (oe && !strcmp(oe, "all"));
         if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered

@@ -62,6 +62,7 @@ struct ZyLaunch {
 };
 
 bool       zy_supported(int dtype, int n1, int n2);
+int        zy_col_threads(int n1);
 long long  zy_grid();
 unsigned   zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers);
 unsigned   zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk);

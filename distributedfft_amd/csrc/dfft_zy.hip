@@ -54,7 +54,8 @@ typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
 // un-packed launches take tiles of TWO lines (16 columns), which restores the 512 threads and the 64 KiB.  Packed launches keep one
 // line (a rotated tile position is a multiple of one line, so a wider tile could straddle the end of a row).
 template <class PY, bool PACK> struct ZyTile {
-    static constexpr int CB = (!PACK && PY::T < 64) ? 8 * (64 / PY::T) : 8;
+    static constexpr bool WIDE = !PACK && PY::T < 64 && (size_t)PY::N * (8 * (64 / PY::T)) * sizeof(double2) <= 128 * 1024;  // (768 points: 192 KiB, no)
+    static constexpr int  CB = WIDE ? 8 * (64 / PY::T) : 8;
     static constexpr int THREADS = CB * PY::T;
 };
 
@@ -70,14 +71,20 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     using V = double2;
     constexpr int CB = ZyTile<PY, PACK>::CB;  // columns per tile: one cache line, or two for 256-point Y axes (ZyTile)
     constexpr int THREADS = ZyTile<PY, PACK>::THREADS;
-    constexpr int N2 = PZ::N, N1 = PY::N, E = PZ::E, TZ = PZ::T, TY = PY::T;
-    static_assert(PZ::E == PY::E, "one register set serves both item kinds");
+    // points per thread: 8 on both axes for 256 / 512 points; a 768-point Y axis (round 5, BASELINE config 4) holds 24 per thread in a
+    // 256-thread workgroup -- one register set sized for the larger kind serves both kinds of unit
+    constexpr int N2 = PZ::N, N1 = PY::N, EZ = PZ::E, EY = PY::E, E = EZ > EY ? EZ : EY, TZ = PZ::T, TY = PY::T;
     static_assert(TZ <= 64 && 64 % TZ == 0 && THREADS % TZ == 0, "rows: one FFT inside one wavefront");
     constexpr int GR = THREADS / TZ;  // rows per row unit
     static_assert(N1 % GR == 0 && N2 % CB == 0, "a plane must split into whole units");
     constexpr unsigned UZ = N1 / GR, UY = N2 / CB;
     constexpr unsigned UA = DIR > 0 ? UZ : UY, UB = DIR > 0 ? UY : UZ, BB = UA + UB;  // producer / consumer units per plane
-    constexpr bool     TWPOW = true;
+    // twiddles exactly as the library's two-launch kernels of the same plans keep them (KernelGeom::TWMODE), so that the arithmetic is
+    // the same to the bit: per-thread power sets in registers where a thread needs at most 16 of them, otherwise (768 points: 37) a
+    // stage-major copy of the table in LDS, read in plain (non-power) form
+    constexpr int      TWMZ = TwTotal<PZ, true>::value <= 16 ? TW_REG : TW_LDS, TWMY = TwTotal<PY, true>::value <= 16 ? TW_REG : TW_LDS;
+    constexpr bool     TWPZ = TWMZ == TW_REG, TWPY = TWMY == TW_REG;
+    constexpr size_t   TWZ_BYTES = TWMZ == TW_LDS ? (size_t)N2 * sizeof(V) : 0, TWY_BYTES = TWMY == TW_LDS ? (size_t)N1 * sizeof(V) : 0;
     constexpr int      ROW_LDS = N2 + N2 / 8;  // padded row (lds_index<1, true>)
 // row pitch of w: the compile-time N2, or the launch parameter of the -DDFFT_ZY_ROW_PITCH=1 build (dfft_zy.h)
 #if DFFT_ZY_ROW_PITCH
@@ -88,17 +95,29 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     unsigned* shw = reinterpret_cast<unsigned*>(dfft_smem);  // [0] ticket broadcast, [1] dependency state
-    V*        lds = reinterpret_cast<V*>(dfft_smem + 64);
+    V*        ldstwz = reinterpret_cast<V*>(dfft_smem + 64);
+    V*        ldstwy = reinterpret_cast<V*>(dfft_smem + 64 + TWZ_BYTES);
+    V*        lds = reinterpret_cast<V*>(dfft_smem + 64 + TWZ_BYTES + TWY_BYTES);
 
     const int tid = threadIdx.x;
     const int gz = tid / TZ, jz = tid % TZ;  // row unit: row gz of the unit, butterfly id jz
     const int cy = tid % CB, jy = tid / CB;  // column unit: column cy of the tile, butterfly id jy
     V*        lds_row = lds + gz * ROW_LDS;
 
-    constexpr int TWNZ = TwTotal<PZ, TWPOW>::value, TWNY = TwTotal<PY, TWPOW>::value;
-    V twzr[TWNZ > 0 ? TWNZ : 1], twyr[TWNY > 0 ? TWNY : 1];
-    load_twiddles<V, PZ, 0, DIR, TWPOW>(twzr, twz, jz);
-    load_twiddles<V, PY, 0, DIR, TWPOW>(twyr, twy, jy);
+    constexpr int TWNZ = TWPZ ? TwTotal<PZ, true>::value : 0, TWNY = TWPY ? TwTotal<PY, true>::value : 0;
+    V        twzr[TWNZ > 0 ? TWNZ : 1], twyr[TWNY > 0 ? TWNY : 1];
+    const V *twzp = twzr, *twyp = twyr;
+    if constexpr (TWPZ) load_twiddles<V, PZ, 0, DIR, true>(twzr, twz, jz);
+    else {
+        fill_stage_major<V, PZ, 0, DIR>(ldstwz, twz, tid, THREADS);
+        twzp = ldstwz;
+    }
+    if constexpr (TWPY) load_twiddles<V, PY, 0, DIR, true>(twyr, twy, jy);
+    else {
+        fill_stage_major<V, PY, 0, DIR>(ldstwy, twy, tid, THREADS);
+        twyp = ldstwy;
+    }
+    if constexpr (!TWPZ || !TWPY) __syncthreads();
 
     const unsigned CH = chunk;
     const unsigned nchunks = (nplanes + CH - 1) / CH;
@@ -174,10 +193,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     };
     // packed side (PACK): point jy + TY k of a column lies in block (TY k) / pk.blk of the map -- the launcher guarantees
     // pk.blk % TY == 0, so the block term is wave-uniform per k (computed once) -- plus one per-thread term and the tile's base
-    unsigned pk_uni[PACK ? E : 1];
+    unsigned pk_uni[PACK ? EY : 1];
     if constexpr (PACK) {
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
+        for (int k = 0; k < EY; ++k) {
             const int ib = (TY * k) / pk.blk;
             pk_uni[k] = (unsigned)(block_term(pk, ib) + (long long)(TY * k - ib * pk.blk) * pk.stride);
         }
@@ -194,11 +213,11 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if constexpr (ROWS_PRODUCE) {
             const V* ip = src + (long long)plane * src_plane + (long long)(un * GR + gz) * N2 + jz;
 #pragma unroll
-            for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + TZ * k);  // streamed input
+            for (int k = 0; k < EZ; ++k) d[k] = gload<true>(ip + TZ * k);  // streamed input
         } else {
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
+            for (int k = 0; k < EZ; ++k) {
                 const unsigned elem = (unsigned)((un * GR + gz) * DFFT_ZY_WP + jz + TZ * k);
                 d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
             }
@@ -208,14 +227,14 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if constexpr (ROWS_PRODUCE) {
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
+            for (int k = 0; k < EZ; ++k) {
                 const unsigned elem = (unsigned)((un * GR + gz) * DFFT_ZY_WP + jz + TZ * k);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
             }
         } else {
             V* op = dst + (long long)plane * dst_plane + (long long)(un * GR + gz) * N2 + jz;
 #pragma unroll
-            for (int k = 0; k < E; ++k) op[TZ * k] = v[k];
+            for (int k = 0; k < EZ; ++k) op[TZ * k] = v[k];
         }
     };
     // ---- column units (Y), in place on w: forward sc1 loads / plain stores, backward plain loads / sc1 stores
@@ -223,33 +242,33 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if constexpr (ROWS_PRODUCE) {
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
+            for (int k = 0; k < EY; ++k) {
                 const unsigned elem = (unsigned)((jy + TY * k) * DFFT_ZY_WP + un * CB + cy);
                 d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1 */));
             }
         } else if constexpr (PACK) {
             const V* ip = src + pk_base(plane, un);  // the receive buffer, written before this launch: streamed, plain visibility
 #pragma unroll
-            for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + pk_uni[k]);
+            for (int k = 0; k < EY; ++k) d[k] = gload<true>(ip + pk_uni[k]);
         } else {
             const V* ip = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
-            for (int k = 0; k < E; ++k) d[k] = ip[(long long)(TY * k) * DFFT_ZY_WP];
+            for (int k = 0; k < EY; ++k) d[k] = ip[(long long)(TY * k) * DFFT_ZY_WP];
         }
     };
     auto store_cols = [&](unsigned plane, unsigned un, const V* v) {
         if constexpr (ROWS_PRODUCE && PACK) {
             V* op = dst + pk_base(plane, un);  // the send buffer: not read again by this device, streamed out
 #pragma unroll
-            for (int k = 0; k < E; ++k) gstore<true>(op + pk_uni[k], v[k]);
+            for (int k = 0; k < EY; ++k) gstore<true>(op + pk_uni[k], v[k]);
         } else if constexpr (ROWS_PRODUCE) {
             V* op = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
-            for (int k = 0; k < E; ++k) op[(long long)(TY * k) * DFFT_ZY_WP] = v[k];
+            for (int k = 0; k < EY; ++k) op[(long long)(TY * k) * DFFT_ZY_WP] = v[k];
         } else {
             const __amdgpu_buffer_rsrc_t rs = wrsrc(plane);
 #pragma unroll
-            for (int k = 0; k < E; ++k) {
+            for (int k = 0; k < EY; ++k) {
                 const unsigned elem = (unsigned)((jy + TY * k) * DFFT_ZY_WP + un * CB + cy);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 16 /* sc1 */);
             }
@@ -267,10 +286,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     };
     auto compute_unit = [&](const Item& it, V* v) {
         if (is_rows(it.kind)) {
-            run_stages<V, PZ, 0, DIR, 1, true, true, TW_REG, TWPOW>(v, twzr, lds_row, jz, 0);
+            run_stages<V, PZ, 0, DIR, 1, true, true, TWMZ, TWPZ>(v, twzp, lds_row, jz, 0);
         } else {
             __syncthreads();  // the LDS rows of an earlier row unit are no longer read
-            run_stages<V, PY, 0, DIR, CB, false, false, TW_REG, TWPOW>(v, twyr, lds, jy, cy);
+            run_stages<V, PY, 0, DIR, CB, false, false, TWMY, TWPY>(v, twyp, lds, jy, cy);
         }
     };
     auto store_unit = [&](const Item& it, const V* v) {
@@ -390,7 +409,9 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
     constexpr int    CB = ZyTile<PY, PACK>::CB, THREADS = ZyTile<PY, PACK>::THREADS, GR = THREADS / PZ::T;
     constexpr unsigned UA = DIR > 0 ? (unsigned)(PY::N / GR) : (unsigned)(PZ::N / CB);  // producer units per plane, as in the kernel
     constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * CB * sizeof(double2);
-    constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
+    constexpr size_t TW_BYTES = (TwTotal<PZ, true>::value > 16 ? (size_t)PZ::N * sizeof(double2) : 0) + (TwTotal<PY, true>::value > 16 ? (size_t)PY::N * sizeof(double2) : 0);
+    constexpr size_t LDS_BYTES = 64 + TW_BYTES + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
+    static_assert(LDS_BYTES <= 160 * 1024, "a unit and the twiddle tables must fit the LDS of a CU");
     auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
@@ -421,18 +442,32 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
 
 using P256 = Plan<256, 8, 8, 8, 4>;
 using P512 = Plan<512, 8, 8, 8, 8>;
+using P768 = Plan<768, 24, 8, 8, 4, 3>;  // the column plan of dfft_plans.h (24 points x 32 threads: 256-thread units, 96 KiB tiles)
+
+// host-side mirror of the kernel's geometry: threads per workgroup, columns per tile, rows per row unit
+struct ZyGeom {
+    int threads, cb, gr;
+};
+ZyGeom zy_geom(int n1, int n2, int packed) {
+    const int ey = n1 == 768 ? 24 : 8, ty = n1 / ey, tz = n2 / 8;
+    const int cb = (!packed && ty < 64) ? 8 * (64 / ty) : 8;  // ZyTile
+    if (n1 == 768) return ZyGeom{8 * ty, 8, 8 * ty / tz};      // (a two-line tile of 768 points would not fit the LDS)
+    return ZyGeom{cb * ty, cb, cb * ty / tz};
+}
 
 }  // namespace
 
-bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512) && (n2 == 256 || n2 == 512); }
+// fp64; Y axis of 256, 512 or (round 5) 768 points, Z axis of 256 or 512 points
+bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512 || (n1 == 768 && n2 == 512)) && (n2 == 256 || n2 == 512); }
+// threads that share one column FFT of the Y axis: a destination block of the packed layout must be a whole number of them
+int zy_col_threads(int n1) { return n1 == 768 ? 32 : n1 / 8; }
 
 // workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
 // advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.
 long long zy_grid() { return device_info().cus; }
 unsigned  zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers) {
-    const int      ty = n1 / 8, tz = n2 / 8, cb = (!packed && ty < 64) ? 8 * (64 / ty) : 8;  // ZyTile
-    const int      threads = cb * ty, gr = threads / tz;
-    const unsigned uz = (unsigned)(n1 / gr), uy = (unsigned)(n2 / cb);
+    const ZyGeom   g = zy_geom(n1, n2, packed);
+    const unsigned uz = (unsigned)(n1 / g.gr), uy = (unsigned)(n2 / g.cb);
     if (producers) *producers = dir > 0 ? uz : uy;
     return uz + uy;
 }
@@ -458,6 +493,7 @@ hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     DFFT_ZY_CASE(256, 256, P256, P256)
     DFFT_ZY_CASE(512, 256, P512, P256)
     DFFT_ZY_CASE(256, 512, P256, P512)
+    DFFT_ZY_CASE(512, 768, P512, P768)
 #undef DFFT_ZY_CASE
     return hipErrorInvalidValue;
 }

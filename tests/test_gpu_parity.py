@@ -289,7 +289,8 @@ def test_untimed_executes_back_to_back_are_bit_identical(gpu):
             pl.destroy()
 
 
-@pytest.mark.parametrize("N,chunk", [((16, 256, 256), 5), ((12, 512, 256), 4), ((9, 256, 512), 2), ((70, 512, 512), 64), ((512, 256, 256), 0)])
+@pytest.mark.parametrize("N,chunk", [((16, 256, 256), 5), ((12, 512, 256), 4), ((9, 256, 512), 2), ((70, 512, 512), 64), ((512, 256, 256), 0),
+                                     ((10, 768, 512), 3), ((64, 768, 512), 0)])   # 768-point Y axis: config 4's planes (round 5)
 def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
     """t0 as ONE persistent launch (dfft_zy.hip: ticket-ordered row and column units, sc1 hand-off through the hand-over buffer)
     against the two launches per cache chunk it replaces: with several chunks and a ragged last chunk, in both directions, also
@@ -479,7 +480,8 @@ def test_one_launch_t0_failure_is_collective(gpu, monkeypatch):
 
 
 @pytest.mark.parametrize("rot", ["0", "1"])
-@pytest.mark.parametrize("N,P", [((8, 256, 256), 2), ((16, 256, 512), 4), ((16, 512, 256), 2), ((32, 256, 256), 8), ((24, 512, 512), 4)])
+@pytest.mark.parametrize("N,P", [((8, 256, 256), 2), ((16, 256, 512), 4), ((16, 512, 256), 2), ((32, 256, 256), 8), ((24, 512, 512), 4),
+                                 ((16, 768, 512), 8), ((8, 768, 512), 2)])   # config 4's planes: blocks of 96 / 384 rows per destination
 def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatch):
     """P > 1: the one-launch YZ stage stores its column results straight into the packed (and, with DFFT_ROT=1, row-rotated) send
     layout, the inverse reads the packed receive layout -- whole slabs in the serial pipeline, X-plane parts in the overlapped

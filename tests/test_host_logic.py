@@ -308,7 +308,10 @@ def test_headline_kernels_do_not_spill():
     # the one-launch YZ stage (csrc/dfft_zy.hip; the headline's t0): every instantiation, and the lazy-publish kernels with room to
     # spare (they keep the products of their twiddle powers out of the unit loop's invariants: 192-200 registers)
     rows = kr.zy_table()
-    assert len(rows) == 32, len(rows)   # 4 plane shapes x 2 directions x packed / un-packed x eager / lazy
+    assert len(rows) == 40, len(rows)   # 5 plane shapes x 2 directions x packed / un-packed x eager / lazy
     for tag, vgpr, scratch, _ in rows:
         assert scratch == 0, f"{tag}: {scratch} bytes of scratch"
-        assert vgpr <= (224 if tag.endswith("lazy") else 256), f"{tag}: {vgpr} registers"
+        if " Y=768 " in tag:            # 256-thread units (one wave per SIMD): 24 points + 24 prefetched, AGPR-backed, up to 512
+            assert vgpr <= 448, f"{tag}: {vgpr} registers"
+        else:
+            assert vgpr <= (224 if tag.endswith("lazy") else 256), f"{tag}: {vgpr} registers"

@@ -81,7 +81,7 @@ def zy_table():
     for m in re.finditer(r"^(_ZN4dfft\w*zy_chunk_kernel\w+): ", asm, re.M):
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
-        lens = re.findall(r"ILi(\d+)ELi8E", name)  # Plan<N, 8, ...> of the Z and (when different) Y axis
+        lens = re.findall(r"ILi(\d+)ELi(?:8|24)E", name)  # Plan<N, 8 | 24, ...> of the Z and (when different) Y axis
         mm = re.search(r"Li(n?1)ELb([01])ELb([01])E", name)
         if not lens or not mm:
             continue
