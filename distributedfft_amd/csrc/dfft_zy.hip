@@ -31,6 +31,7 @@
 // The plan uses the stage by itself on every single-GPU plan it is built for (since round 4: two-line column tiles for 256-point Y
 // axes, ZyTile below) and on P > 1 plans with 512 x 512-point planes (dfft_plan.cpp, profiles/r04/README.md sections 1-2).
 #include "dfft_fft_impl.h"
+#include "dfft_plans.h"
 #include "dfft_zy.h"
 
 namespace dfft {
@@ -442,14 +443,22 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
 
 using P256 = Plan<256, 8, 8, 8, 4>;
 using P512 = Plan<512, 8, 8, 8, 8>;
-using P768 = Plan<768, 24, 8, 8, 4, 3>;  // the column plan of dfft_plans.h (24 points x 32 threads: 256-thread units, 96 KiB tiles)
+// the library's column plan for 768 points (dfft_plans.h), so that the arithmetic is the two-launch path's: 24 points x 32 threads
+// (256-thread units) or, -DDFFT_768_E12=1, 12 points x 64 threads (512-thread units like the other plane shapes)
+#if DFFT_768_E12
+using P768 = Plan<768, 12, 4, 4, 4, 4, 3>;
+constexpr int ZY_E768 = 12;
+#else
+using P768 = Plan<768, 24, 8, 8, 4, 3>;
+constexpr int ZY_E768 = 24;
+#endif
 
 // host-side mirror of the kernel's geometry: threads per workgroup, columns per tile, rows per row unit
 struct ZyGeom {
     int threads, cb, gr;
 };
 ZyGeom zy_geom(int n1, int n2, int packed) {
-    const int ey = n1 == 768 ? 24 : 8, ty = n1 / ey, tz = n2 / 8;
+    const int ey = n1 == 768 ? ZY_E768 : 8, ty = n1 / ey, tz = n2 / 8;
     const int cb = (!packed && ty < 64) ? 8 * (64 / ty) : 8;  // ZyTile
     if (n1 == 768) return ZyGeom{8 * ty, 8, 8 * ty / tz};      // (a two-line tile of 768 points would not fit the LDS)
     return ZyGeom{cb * ty, cb, cb * ty / tz};
@@ -460,7 +469,7 @@ ZyGeom zy_geom(int n1, int n2, int packed) {
 // fp64; Y axis of 256, 512 or (round 5) 768 points, Z axis of 256 or 512 points
 bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512 || (n1 == 768 && n2 == 512)) && (n2 == 256 || n2 == 512); }
 // threads that share one column FFT of the Y axis: a destination block of the packed layout must be a whole number of them
-int zy_col_threads(int n1) { return n1 == 768 ? 32 : n1 / 8; }
+int zy_col_threads(int n1) { return n1 == 768 ? 768 / ZY_E768 : n1 / 8; }
 
 // workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
 // advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.

@@ -17,7 +17,7 @@ units.append((B.CSRC / "dfft_zy.hip", obj / "dfft_zy.o", flags))  # the one-laun
 units.append((B.CSRC / "dfft_plan.cpp", obj / "dfft_plan.o", ["-x", "hip"] + flags))  # ... some of which the plan has to know (DFFT_ZY_ROW_PITCH)
 with ThreadPoolExecutor(max_workers=8) as ex:
     list(ex.map(lambda u: B._run([B.HIPCC] + B.COMMON + u[2] + ["-c", str(u[0]), "-o", str(u[1])]), units))
-others = [str(B.OBJ / f"{n}.o") for n in ("dfft_kernels", "dfft_generic", "dfft_long", "dfft_exchange", "dfft_bootstrap", "dfft_alloc")]
+others = [str(B.OBJ / f"{n}.o") for n in ("dfft_kernels", "dfft_generic", "dfft_long", "dfft_exchange", "dfft_bootstrap", "dfft_alloc", "dfft_trace")]
 tl = B._torch_lib_dir()
 out = B.LIBDIR / f"libdfft_variant_{name}.so"
 B._run(["g++", "-shared", "-fPIC", "-o", str(out)] + [str(u[1]) for u in units] + others +
