@@ -240,6 +240,7 @@ struct dfft_plan_s {
     unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
     bool                    zy_lazy = false;           // lazy-publish form of the one-launch kernel (un-packed launches; DFFT_ZY_LAZY=0: eager)
+    bool                    zy_inv_rows_first = true;  // backward single-GPU plans: inverse stage rows first (DFFT_ZY_INV_ROWS_FIRST=0: columns first)
     int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
     int                     grid_x = 0, grid_y = 0, grid_z = 0;  // DFFT_X_GRID / DFFT_Y_GRID / DFFT_Z_GRID when the plan was created (0 = no cap)
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
@@ -468,8 +469,9 @@ static long long zy_phase_planes(const dfft_plan_s* p, long long nx) {
 // t0 (or its inverse) of planes [x0, x0 + nx) as one launch (dfft_zy.hip).
 //   forward : Z rows src -> w, Y columns w -> w in place, or (packed) w -> the packed send layout in `other`
 //   backward: Y columns w -> w in place, or (packed) the packed receive layout in `other` -> w; then Z rows w -> dst
+// structure: 0 = the plan's direction; +1 on a backward plan = the inverse stage rows first (src = the hand-over buffer, w = the result buffer)
 static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w_plane, void* dst, void* other, bool packed, long long x0,
-                           long long nx) {
+                           long long nx, int structure = 0) {
     if (nx <= 0) return DFFT_OK;
     const void *twz = nullptr, *twy = nullptr;
     DFFT_TRY(get_twiddles((int)p->N[2], p->dtype, &twz));
@@ -479,11 +481,13 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.dtype = p->dtype;
     L.n1 = (int)p->N[1];
     L.n2 = (int)p->N[2];
-    L.dir = p->direction;
+    L.dir = structure ? structure : p->direction;
+    L.sign = p->direction;
     L.src = src;
     L.w = w;
     L.dst = dst;
     L.src_plane = L.dst_plane = p->N[1] * p->N[2];
+    if (structure > 0 && p->direction < 0) L.src_plane = p->wl.plane;  // rows read the (plane-padded) hand-over buffer
     L.w_plane = w_plane; DFFT_ZY_SET_PITCH(L, (p->wbuf && w == p->wbuf) ? p->wl.pitch : p->N[2]);
     L.plane0 = x0;
     L.nplanes = nx;
@@ -779,7 +783,10 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     const bool      chunked = cp < p->xs || p->xs * n1 * n2 * (long long)elem_bytes(p->dtype) >= (64ll << 20);
     const bool one_launch = p->zy_on && fused;
     // Y columns (in place on the intermediate, or unpacking the receive buffer into it), then Z rows into the result: one launch
-    if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, fused ? ydst : ybuf, yl.plane, ybuf, y_unpacks ? p->buf1 : nullptr, y_unpacks, 0, p->xs));
+    // single-GPU plans with a hand-over buffer: rows first (dfft_zy.hip, SIGN) -- Z rows hand-over buffer -> result buffer, Y columns in place
+    // on the result buffer; the transform is the same, its strided side moves from HBM reads to the cache-resident chunk
+    if (one_launch && p->zy_inv_rows_first && xw && p->zy_lazy) DFFT_TRY(launch_zy_stage(p, p->wbuf, ybuf, n1 * n2, nullptr, nullptr, false, 0, p->xs, +1));
+    else if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, fused ? ydst : ybuf, yl.plane, ybuf, y_unpacks ? p->buf1 : nullptr, y_unpacks, 0, p->xs));
     for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
@@ -1198,6 +1205,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         else if (xv && (!strcmp(xv, "fullearly") || !strcmp(xv, "early"))) p->x_hints = FFT_HINT_EARLY_WAIT;
         const char* zl = getenv("DFFT_ZY_LAZY");
         p->zy_lazy = !(zl && *zl == '0');  // default on: t0 of 512^3 fp64 1.278 -> 1.163 ms (profiles/r03/experiments/variant_ab.log)
+        const char* rf = getenv("DFFT_ZY_INV_ROWS_FIRST");
+        p->zy_inv_rows_first = !(rf && *rf == '0');
     }
     {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on

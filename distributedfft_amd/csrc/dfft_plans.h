@@ -10,10 +10,13 @@
 // upload); contiguous rows of 4096 and 3125 points use plans of their own (dfft_fft_inst.hip: 8 and 5 points per thread).
 #pragma once
 
-// 768 points (config 4's Y axis): 24 points x 32 threads per column -- a 256-thread workgroup per 8-column tile.  -DDFFT_768_E12=1 builds
-// the measurement variant 12 points x 64 threads (512-thread workgroups, radix 4 4 4 4 3: one exchange more).
+// 768 points (config 4's Y axis): 12 points x 64 threads per column (radix 4 4 4 4 3) -- a 512-thread workgroup per 8-column tile, the
+// geometry of every other plane shape of the one-launch YZ stage (dfft_zy.hip), which is what this plan is chosen for: as a two-launch
+// column kernel it measures equal to 24 points x 32 threads (radix 8 8 4 3, 256-thread workgroups; profiles/r04/experiments/
+// lib_ab_768_e12.log, profiles/r05/experiments/variant_ab_768_e12.log), inside the one-launch stage 24 x 32 leaves four waves per CU for
+// the row units and loses 20 % (profiles/r05/README.md section 3).  -DDFFT_768_E12=0 builds the 24-point plan.
 #ifndef DFFT_768_E12
-#define DFFT_768_E12 0
+#define DFFT_768_E12 1
 #endif
 #if DFFT_768_E12
 #define DFFT_PLAN_768(X) X(768, 4, 12, 4, 4, 4, 4, 3)

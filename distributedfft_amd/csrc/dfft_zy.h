@@ -39,6 +39,7 @@ struct ZyLaunch {
     int         dtype;      // DType (F64 only)
     int         n1, n2;     // Y and Z lengths
     int         dir;        // +1: Z rows src -> w, then Y columns in place on w;  -1: Y columns in place on w, then Z rows w -> dst
+    int         sign;       // direction of the transform when it is not `dir` (0 = dir): -1 with dir = +1 runs the INVERSE stage rows first (lazy, un-packed)
     const void* src;        // forward: [plane][N1][N2], planes src_plane elements apart
     void*       w;          // hand-over buffer: rows N2 apart, planes w_plane elements apart
     void*       dst;        // backward: [plane][N1][N2], planes dst_plane elements apart

@@ -60,7 +60,12 @@ template <class PY, bool PACK> struct ZyTile {
     static constexpr int THREADS = CB * PY::T;
 };
 
-template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false>
+// SIGN: direction of the TRANSFORM (sign of the twiddles); DIR above is the STRUCTURE -- which kind of unit produces.  They differ in one
+// case (round 5): the inverse YZ stage of a single-GPU plan runs rows first (DIR = +1, SIGN = -1).  The two 1-D transforms of a plane
+// commute, and columns-first makes the column units READ the hand-over buffer from HBM in 128-byte pieces one row apart (the inverse X pass
+// has just written all of it; the counters show 40 % more read latency behind the L2 than in the forward stage, profiles/r05/README.md
+// section 4) where rows-first reads whole rows from HBM and leaves the strided side to the cache-resident chunk, like the forward stage.
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR>
 __global__ void __attribute__((amdgpu_flat_work_group_size(ZyTile<PY, PACK>::THREADS, ZyTile<PY, PACK>::THREADS), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
@@ -108,14 +113,14 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     constexpr int TWNZ = TWPZ ? TwTotal<PZ, true>::value : 0, TWNY = TWPY ? TwTotal<PY, true>::value : 0;
     V        twzr[TWNZ > 0 ? TWNZ : 1], twyr[TWNY > 0 ? TWNY : 1];
     const V *twzp = twzr, *twyp = twyr;
-    if constexpr (TWPZ) load_twiddles<V, PZ, 0, DIR, true>(twzr, twz, jz);
+    if constexpr (TWPZ) load_twiddles<V, PZ, 0, SIGN, true>(twzr, twz, jz);
     else {
-        fill_stage_major<V, PZ, 0, DIR>(ldstwz, twz, tid, THREADS);
+        fill_stage_major<V, PZ, 0, SIGN>(ldstwz, twz, tid, THREADS);
         twzp = ldstwz;
     }
-    if constexpr (TWPY) load_twiddles<V, PY, 0, DIR, true>(twyr, twy, jy);
+    if constexpr (TWPY) load_twiddles<V, PY, 0, SIGN, true>(twyr, twy, jy);
     else {
-        fill_stage_major<V, PY, 0, DIR>(ldstwy, twy, tid, THREADS);
+        fill_stage_major<V, PY, 0, SIGN>(ldstwy, twy, tid, THREADS);
         twyp = ldstwy;
     }
     if constexpr (!TWPZ || !TWPY) __syncthreads();
@@ -194,15 +199,27 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     };
     // packed side (PACK): point jy + TY k of a column lies in block (TY k) / pk.blk of the map -- the launcher guarantees
     // pk.blk % TY == 0, so the block term is wave-uniform per k (computed once) -- plus one per-thread term and the tile's base
-    unsigned pk_uni[PACK ? EY : 1];
+    // 768 points on 12 x 64 threads (config 4: destination blocks of 96 rows at P = 8): blocks are multiples of 32 rows, not of the 64
+    // a wavefront's threads span, so the lower and the upper half of the threads of a column each get a uniform term of their own
+    constexpr bool PK2 = PACK && PY::N == 768 && TY == 64;
+    unsigned       pk_uni[PACK ? EY : 1], pk_uni1[PK2 ? EY : 1];
     if constexpr (PACK) {
 #pragma unroll
         for (int k = 0; k < EY; ++k) {
             const int ib = (TY * k) / pk.blk;
             pk_uni[k] = (unsigned)(block_term(pk, ib) + (long long)(TY * k - ib * pk.blk) * pk.stride);
+            if constexpr (PK2) {
+                const int i1 = (TY * k + 32) / pk.blk;
+                pk_uni1[k] = (unsigned)(block_term(pk, i1) + (long long)(TY * k + 32 - i1 * pk.blk) * pk.stride);
+            }
         }
     }
-    const long long pk_thr = PACK ? (long long)jy * pk.stride + cy : 0ll;
+    const bool      pk_hi = PK2 && jy >= 32;
+    const long long pk_thr = PACK ? (long long)(PK2 ? (jy & 31) : jy) * pk.stride + cy : 0ll;
+    auto            pk_off = [&](int k) -> unsigned {
+        if constexpr (PK2) return pk_hi ? pk_uni1[k] : pk_uni[k];
+        else return pk_uni[k];
+    };
     auto            pk_base = [&](unsigned plane, unsigned un) -> long long {  // tile base: the plane's rows, rotated tile position
         int col = (int)(un * CB);
         if (rm.rot != 0) col = (col + rm.rot * (int)(plane + (unsigned)rm.a0)) & rm.mask;
@@ -250,7 +267,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         } else if constexpr (PACK) {
             const V* ip = src + pk_base(plane, un);  // the receive buffer, written before this launch: streamed, plain visibility
 #pragma unroll
-            for (int k = 0; k < EY; ++k) d[k] = gload<true>(ip + pk_uni[k]);
+            for (int k = 0; k < EY; ++k) d[k] = gload<true>(ip + pk_off(k));
         } else {
             const V* ip = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
@@ -261,7 +278,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         if constexpr (ROWS_PRODUCE && PACK) {
             V* op = dst + pk_base(plane, un);  // the send buffer: not read again by this device, streamed out
 #pragma unroll
-            for (int k = 0; k < EY; ++k) gstore<true>(op + pk_uni[k], v[k]);
+            for (int k = 0; k < EY; ++k) gstore<true>(op + pk_off(k), v[k]);
         } else if constexpr (ROWS_PRODUCE) {
             V* op = w + (long long)plane * w_plane + (long long)jy * DFFT_ZY_WP + un * CB + cy;
 #pragma unroll
@@ -287,10 +304,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     };
     auto compute_unit = [&](const Item& it, V* v) {
         if (is_rows(it.kind)) {
-            run_stages<V, PZ, 0, DIR, 1, true, true, TWMZ, TWPZ>(v, twzp, lds_row, jz, 0);
+            run_stages<V, PZ, 0, SIGN, 1, true, true, TWMZ, TWPZ>(v, twzp, lds_row, jz, 0);
         } else {
             __syncthreads();  // the LDS rows of an earlier row unit are no longer read
-            run_stages<V, PY, 0, DIR, CB, false, false, TWMY, TWPY>(v, twyp, lds, jy, cy);
+            run_stages<V, PY, 0, SIGN, CB, false, false, TWMY, TWPY>(v, twyp, lds, jy, cy);
         }
     };
     auto store_unit = [&](const Item& it, const V* v) {
@@ -406,14 +423,14 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     }
 }
 
-template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
     constexpr int    CB = ZyTile<PY, PACK>::CB, THREADS = ZyTile<PY, PACK>::THREADS, GR = THREADS / PZ::T;
     constexpr unsigned UA = DIR > 0 ? (unsigned)(PY::N / GR) : (unsigned)(PZ::N / CB);  // producer units per plane, as in the kernel
     constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * CB * sizeof(double2);
     constexpr size_t TW_BYTES = (TwTotal<PZ, true>::value > 16 ? (size_t)PZ::N * sizeof(double2) : 0) + (TwTotal<PY, true>::value > 16 ? (size_t)PY::N * sizeof(double2) : 0);
     constexpr size_t LDS_BYTES = 64 + TW_BYTES + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
     static_assert(LDS_BYTES <= 160 * 1024, "a unit and the twiddle tables must fit the LDS of a CU");
-    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY>;
+    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY, SIGN>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int                      dev = 0;
@@ -426,7 +443,8 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false> hipError_t 
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    if (PACK && (L.pk.blk <= 0 || L.pk.blk % PY::T != 0 || L.pk.last_delta != 0)) return hipErrorInvalidValue;
+    constexpr int PK_GRAIN = (PY::N == 768 && PY::T == 64) ? 32 : PY::T;  // (PK2 in the kernel)
+    if (PACK && (L.pk.blk <= 0 || L.pk.blk % PK_GRAIN != 0 || L.pk.last_delta != 0)) return hipErrorInvalidValue;
     // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing -- nor do two or three of the
     // 256-thread workgroups of 256-point Y axes, profiles/r03/experiments/variant_ab_256.log)
     const long long grid = zy_grid();
@@ -469,7 +487,7 @@ ZyGeom zy_geom(int n1, int n2, int packed) {
 // fp64; Y axis of 256, 512 or (round 5) 768 points, Z axis of 256 or 512 points
 bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512 || (n1 == 768 && n2 == 512)) && (n2 == 256 || n2 == 512); }
 // threads that share one column FFT of the Y axis: a destination block of the packed layout must be a whole number of them
-int zy_col_threads(int n1) { return n1 == 768 ? 768 / ZY_E768 : n1 / 8; }
+int zy_col_threads(int n1) { return n1 == 768 ? 32 : n1 / 8; }  // (768 points: either column plan takes destination blocks of whole 32 rows)
 
 // workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
 // advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.
@@ -493,6 +511,8 @@ hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
 #endif
 #define DFFT_ZY_CASE(NZ, NY, PZ_, PY_)                                                                                           \
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
+        if (L.lazy && !L.packed && L.dir > 0 && L.sign < 0) return launch_zy_t<PZ_, PY_, +1, false, true, -1>(L, stream);                         \
+        if (L.sign != 0 && L.sign != L.dir) return hipErrorInvalidValue;                                                                        \
         if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream); \
         if (L.lazy) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
         if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \
