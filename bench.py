@@ -25,9 +25,11 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
-# best 2 GiB -> 2 GiB copy measured on this GPU model (profiles/r02/README.md: 5.95 TB/s over 280 copy configurations; the
-# guide's 6.29 TB/s float4 figure is reached only by working sets that partly live in the Infinity Cache)
+# best 2 GiB -> 2 GiB copy measured on this GPU model by this repository (round 2: 5.95 TB/s over 280 copy configurations; round 5,
+# tools/l2probe.hip: 5.73-5.82 TB/s for a plain persistent copy over 12 buffer pairs, 6.40 TB/s when both sides fit the Infinity
+# Cache -- profiles/r05/README.md section 2) and the guide's own float4 copy figure (MI355X_MICROARCH.md: 6.29 TB/s); both are quoted
 HBM_COPY_CEILING_GBS = 5950.0
+HBM_GUIDE_COPY_GBS = 6290.0
 
 
 def parse_size(s: str):
@@ -584,6 +586,7 @@ def main():
             zy = 2 * local_bytes / float(stage[0]) / 1e9
             roof = {"bound": "hbm", "kernel": names[2], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
+                    "frac_of_guide_copy_figure": round(ach / HBM_GUIDE_COPY_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
                     "device_copy_of_same_bytes_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                     "avg_launch_ms": round(x_s * 1e3, 4),
@@ -634,6 +637,7 @@ def main():
             ach = local_bytes / kern[k] / 1e9
             roof = {"bound": "hbm", "kernel": names[k], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4),
+                    "frac_of_guide_copy_figure": round(ach / HBM_GUIDE_COPY_GBS, 4),
                     "traffic": None, "algorithmic_bytes_per_launch": local_bytes,
                     "device_copy_of_same_bytes_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                     "avg_launch_ms": round(float(kern[k]) * 1e3, 4),

@@ -1226,9 +1226,13 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         //    eagerly): per rank at 512^3 fp64, exchange switched off, t0 / back-to-back P = 2 0.690 / 1.052 -> 0.630 / 0.94, P = 4
         //    0.343 / 0.512 -> 0.32 / 0.492, P = 8 0.174 / 0.255 -> 0.157 / 0.248 (experiments/lib_ab_lazy_packed.log) -- used by itself
         //    for 512 x 512-point planes (packed tiles stay one line wide, so planes with a 256-point axis keep two launches).
-        //  * round 5: planes with a 768-point Y axis (BASELINE config 4: 768 x 512; 24 points per thread, 256-thread units, the twiddle
-        //    table of the Y axis in LDS like the two-launch kernel's), single-GPU and packed.
-        const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512) || (oe && !strcmp(oe, "all"));
+        //  * round 5: planes with a 768-point Y axis (BASELINE config 4's 768 x 512 planes; 12 points x 64 threads, twiddle table of the Y
+        //    axis in LDS like the two-launch kernel's).  t0 / back-to-back ms, two launches per chunk -> one launch, 1024 x 768 x 512 fp64:
+        //    P = 1 4.49 / 7.23 -> 3.99 / 6.73, per rank at P = 4 (192-row destination blocks) 1.12 / 1.84 -> 1.06 / 1.74 -- but at P = 8
+        //    (96-row blocks, two offset tables per thread half) 0.57-0.60 / 0.91-0.93 -> 0.62 / 0.94 whatever the phase size
+        //    (profiles/r05/experiments/variant_ab_768_final.log, c4_p8_one_launch_sweep.log): used by itself where a destination block is
+        //    whole 64-row strides of the column unit, i.e. up to P = 4 for this axis.
+        const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512 && ysub % 64 == 0) || (oe && !strcmp(oe, "all"));
         if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
