@@ -166,9 +166,13 @@ int dfft_plan_sync(dfft_plan_t plan);
  * usually do not.  dfft_plan_tune times that ONE kernel -- seven launches of ~0.7 ms per candidate, no complete transforms --
  * on the current buffer and on fresh allocations of the same size made one after the other and all kept until the end (memory
  * is handed out in runs of 2 ... 36 such allocations that behave alike, so a dense walk cannot step over a run), stops as soon
- * as two candidates differ by 3 %, keeps the fastest and frees everything else.  Bounds: DFFT_TUNE_TRIES candidates (default
- * 128) and a transient footprint of at most 70 % of the free device memory; worst case about a second at 512^3 fp64.  The probe
- * launches overwrite the result buffer (forward plans) with garbage:
+ * as two candidates differ by 3 % and a second timing of the fastest and the slowest confirms a 3.5 % gap, keeps the fastest and frees
+ * everything else.  Bounds: DFFT_TUNE_TRIES candidates and a transient footprint of DFFT_TUNE_MEM_PCT per cent of the FREE device
+ * memory -- by default 32 candidates / 25 %, because other plans and processes may share the GPU, and 128 / 70 % when at least 90 % of
+ * the device's memory is free, i.e. when this process evidently has the GPU to itself (on some boxes 60+ GiB of consecutive
+ * allocations behave alike and the short walk finds no fast buffer: profiles/r04/experiments/tune_check_short_walk.log); worst case
+ * about a second at 512^3 fp64.  The probe launches overwrite the result buffer (forward plans) with garbage -- its contents are set
+ * aside and put back:
  * call it before the first execute, not between an execute and the use of its result.  A no-op for plans without such a
  * buffer (P > 1, un-fused, natural-order, cache-resident sizes) and with DFFT_TUNE=0.  Results of later executes are
  * bit-identical with and without tuning.  The reference-named wrapper fft_mpi_plan_dft_c2c_3d, distFFTOpt, speed3d_c2c and
