@@ -653,7 +653,13 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
 #endif
     constexpr bool WIDE = DFFT_WIDE_PREFETCH && KG::THREADS <= 256 && KG::LDS_BYTES > 80 * 1024 && !GENERAL;
     constexpr bool EARLY = Tune::EARLY_WAIT || (WIDE && DFFT_WIDE_PREFETCH >= 2);
-    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH || WIDE) && KG::THREADS <= 512;
+    // 768 points on 12 points x 64 threads (the library's column plan since round 5): its second register set is 48 VGPRs of 16-byte
+    // points -- over the general bound, but these kernels have the room.  -DDFFT_768_PREFETCH=0 compiles it out (A/B builds).
+#ifndef DFFT_768_PREFETCH
+#define DFFT_768_PREFETCH 1
+#endif
+    constexpr bool P768 = DFFT_768_PREFETCH && P::N == 768 && E == 12 && sizeof(V) == 16;
+    constexpr bool PREFETCH = Tune::PREFETCH && (E * (int)sizeof(V) / 4 <= DFFT_PREFETCH_MAX_REGS || Tune::FULL_PREFETCH || WIDE || P768) && KG::THREADS <= 512;
     // 16 points per thread (1024- and 2048-point columns) without Tune::FULL_PREFETCH: a whole second register set does not fit next
     // to per-point offsets (64 VGPRs: 4.6 -> 3.7 TB/s, round 1), but the kernels leave room for HALF of one -- the first 8 points of
     // the next tile are fetched underneath the current tile's exchanges and stores, the other 8 at the top of the next iteration.

@@ -1371,7 +1371,9 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     // stage that gave up is seen here, before any timing is printed or any result used.  Where the pipeline has not written its own
     // input -- fused single-GPU plans that read `in` or bufferDev1 and work in the hand-over buffer -- the transform is simply run
     // again on two launches per chunk (zy_check has switched the stage off); otherwise the failure is the return code.
-    if (sync && plan->exch && plan->zy_ctl) {
+    if (sync && plan->exch && plan->zy_ctl && plan->direction == DFFT_FORWARD) {
+        // (backward plans run the stage AFTER their exchange: a failure there spoils only the failing rank's own result, which that
+        // rank reports itself below -- no collective needed, none paid)
         // P > 1: the failure is rank-local knowledge, but the exchange has already shipped this rank's invalid data to every peer.
         // Every device of the communicator learns of it here (every plan of the communicator that was BUILT with the stage takes
         // part, whether its own stage is still on or not -- the condition must not depend on a rank's own history), returns an error

@@ -222,6 +222,78 @@ def test_tcp_rendezvous(native_lib, world):
         assert f"BOOT_OK {r} {world}" in o
 
 
+DEAD_PEER_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from distributedfft_amd import _lib
+lib = _lib.load()
+assert lib.dfft_boot_init() == 0, lib.dfft_last_error()
+assert lib.dfft_boot_barrier() == 0
+if lib.dfft_boot_rank() == int(os.environ["DFFT_TEST_SLEEPER"]):
+    time.sleep(60)                      # leaves the collective call sequence: its peers must not wait for ever
+t0 = time.monotonic()
+rc = lib.dfft_boot_barrier()
+print("BARRIER", rc, round(time.monotonic() - t0, 1), lib.dfft_last_error().decode(), flush=True)
+'''
+
+
+@pytest.mark.parametrize("sleeper", [0, 1])
+def test_rendezvous_waits_are_bounded(native_lib, sleeper):
+    """A rank that stops taking part (round 4's "stalls" began with a rank that had died): the others' barrier returns DFFT_ECOMM
+    after DFFT_BOOT_TIMEOUT_S naming the collective, the rank waited for and the reason, and prints the process's last
+    control-plane events (dfft_trace.cpp) -- instead of blocking in recv() for ever."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, DFFT_RANK=str(r), DFFT_WORLD_SIZE="2", DFFT_MASTER_ADDR="127.0.0.1", DFFT_MASTER_PORT=str(port),
+                   DFFT_ROOT=str(ROOT), DFFT_BOOT_TIMEOUT_S="3", DFFT_TEST_SLEEPER=str(sleeper))
+        for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        procs.append(subprocess.Popen([sys.executable, "-c", DEAD_PEER_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    waiter = procs[1 - sleeper]
+    o, e = waiter.communicate(timeout=60)
+    procs[sleeper].kill()
+    procs[sleeper].communicate()
+    line = [l for l in o.splitlines() if l.startswith("BARRIER")][0].split(None, 3)
+    assert int(line[1]) == -5 and 2.0 <= float(line[2]) <= 15.0, o          # DFFT_ECOMM, after about the limit
+    assert f"waiting for rank {sleeper}" in line[3] and "DFFT_BOOT_TIMEOUT_S" in line[3]
+    assert "[dfft trace]" in e and "boot: allreduce/barrier enter" in e
+
+
+def test_rendezvous_rejects_a_stranger_on_its_port(native_lib):
+    """The hello is {magic, rank} and is acknowledged with {magic, world size}: something else that connects to rank 0's port is
+    dropped without failing the job, and a rank that finds a foreign listener on the port keeps trying until the real rank 0 is there."""
+    import socket
+    import time
+    port = _free_port()
+    foreign = socket.socket()                      # a listener that is NOT rank 0 owns the port first
+    foreign.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    foreign.bind(("127.0.0.1", port))
+    foreign.listen(4)
+    env1 = dict(os.environ, DFFT_RANK="1", DFFT_WORLD_SIZE="2", DFFT_MASTER_ADDR="127.0.0.1", DFFT_MASTER_PORT=str(port), DFFT_ROOT=str(ROOT))
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env1.pop(k, None)
+    p1 = subprocess.Popen([sys.executable, "-c", BOOT_WORKER], env=env1, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    c, _ = foreign.accept()                        # rank 1 took the stranger for rank 0 ...
+    c.close()                                      # ... which does not answer with the magic word
+    foreign.close()
+    time.sleep(0.3)
+    p0 = subprocess.Popen([sys.executable, "-c", BOOT_WORKER], env=dict(env1, DFFT_RANK="0"), stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True)
+    time.sleep(0.5)
+    try:                                           # and a stranger knocks at the real rank 0's door
+        s = socket.create_connection(("127.0.0.1", port), timeout=2)
+        s.sendall(b"GET / HTTP/1.0\r\n\r\n")
+        s.close()
+    except OSError:
+        pass
+    for r, p in ((0, p0), (1, p1)):
+        o, e = p.communicate(timeout=120)
+        assert p.returncode == 0, e[-2000:]
+        assert f"BOOT_OK {r} 2" in o
+
+
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_bench_control_plane_dry_run(native_lib, world):
     """bench.py's multi-rank plumbing (torchrun-style env, gloo rendezvous, 128-byte id broadcast, slab bookkeeping),
