@@ -193,7 +193,8 @@ def live_traffic(args, nchunks: int):
                     continue
                 if "TuneTransposedStore" in name and ", 1, false" in name:
                     x.append(val)                      # forward X pass (the tuning's probe launches move the same bytes)
-                elif "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*>", name):  # forward one-launch YZ stage (any variant)
+                elif "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*(, 1)?>", name):  # forward one-launch YZ stage (any variant:
+                    # <PZ, PY, DIR = 1, PACK, LAZY, SIGN = 1>; the inverse stage run rows first is <..., 1, false, true, -1>)
                     zy.append(val)
                 elif ", 1, false, dfft::TuneStreamIn>" in name:
                     rows_.append(val)                  # forward Z rows, one launch per cache chunk

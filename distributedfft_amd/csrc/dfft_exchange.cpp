@@ -153,6 +153,23 @@ int comm_recv_alloc(dfft_comm_t c, const std::string& key, size_t bytes, void** 
     if (c && c->pooled) c->pending[*out] = key + "#" + std::to_string(bytes);
     return DFFT_OK;
 }
+// Is `buf` an allocation of comm_recv_alloc that no peer knows yet (not registered, not from the pool)?  Only such a buffer may still
+// be exchanged for another one (placement of the receive buffer, dfft_plan.cpp); comm_recv_swap does it.
+bool comm_recv_is_fresh(dfft_comm_t c, void* buf) {
+    if (!c || !c->pooled) return true;
+    return c->pending.find(buf) != c->pending.end();
+}
+int comm_recv_swap(dfft_comm_t c, void* old_buf, void* new_buf) {
+    if (c && c->pooled) {
+        auto it = c->pending.find(old_buf);
+        if (it == c->pending.end()) return fail(DFFT_EINVAL, "comm_recv_swap: the buffer is already registered");
+        const std::string key = it->second;
+        c->pending.erase(it);
+        c->pending[new_buf] = key;
+    }
+    DFFT_HIP_TRY(hipFree(old_buf));
+    return DFFT_OK;
+}
 int comm_recv_free(dfft_comm_t c, void* buf) {
     if (!buf) return DFFT_OK;
     if (c && c->pooled) {

@@ -85,6 +85,8 @@ int comm_unregister(dfft_comm_t comm, int me, int reg);
 // whole life and reuse them (dfft_exchange.cpp, comm_recv_alloc); everywhere else these are hipMalloc / hipFree.
 int comm_recv_alloc(dfft_comm_t comm, const std::string& key, size_t bytes, void** out);
 int comm_recv_free(dfft_comm_t comm, void* buf);
+bool comm_recv_is_fresh(dfft_comm_t comm, void* buf);              // not registered with / known to any peer yet
+int comm_recv_swap(dfft_comm_t comm, void* old_buf, void* new_buf);  // frees old_buf, new_buf takes its place (fresh buffers only)
 int comm_kind(dfft_comm_t comm);  // 0 local, 1 rccl, 2 ipc (host-synchronised), 3 ipc (stream-ordered)
 bool comm_is_async(dfft_comm_t comm);  // exchanges are enqueued on the stream (rccl, ipc-async) instead of blocking the host
 int comm_check(dfft_comm_t comm);      // error reported by an asynchronous exchange since the last check

@@ -800,6 +800,154 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     return DFFT_OK;
 }
 
+// Placement of the RECEIVE buffer of a P > 1 forward plan -- the P > 1 twin of dfft_plan_tune.  The X pass reads
+// the receive buffer and writes the caller's `out`; like the hand-over buffer of a single-GPU plan the two normally come out of the
+// same region of physical memory, the slow mode of any kernel that streams from one buffer into another.  The
+// peers push into this buffer, so it has to be chosen BEFORE it is registered with the communicator: here, inside dfft_plan_create,
+// for out-of-place fused forward plans whose received slab is larger than the Infinity Cache, and only while the buffer is still
+// unknown to the peers (a pooled buffer of an IPC communicator was placed when its first plan was created).  Same walk as
+// dfft_plan_tune: the plan's X-pass launches alone on the current buffer and on fresh allocations made one after the other, all
+// kept until the end; stops at a confirmed 3.5 % gap; the probes write garbage into `out`, whose contents are set aside and put back.
+// Every rank walks on its own (the registration that follows is the collective).
+// Measured (round 5, per rank of 512^3 fp64 with the exchange switched off, profiles/r05/README.md section 6): X pass at P = 2 0.373 ->
+// 0.341 ms (-8 %), at P = 4 0.176 vs 0.177 (nothing: no candidate in 5-8 differs from the first by more than noise once the pass runs
+// inside the pipeline), config 4's rank at P = 8: 128 candidates within 3 % of each other.  A gain in one shape, plan-time cost and a
+// transient footprint of many slabs in all of them, on a path that has never run on real links: OPT-IN, DFFT_TUNE_RECV=1 (at most
+// DFFT_TUNE_TRIES, default 24, candidates).
+static int place_recv_buffer(dfft_plan_s* p) {
+    const char* te = getenv("DFFT_TUNE_RECV");
+    if (!(te && *te == '1')) return DFFT_OK;
+    if (!p->exch || p->P < 2 || p->direction != DFFT_FORWARD || p->inplace || p->long_axis || (p->flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)))
+        return DFFT_OK;
+    const size_t eb = elem_bytes(p->dtype);
+    if ((size_t)p->N[0] * p->ys * p->N[2] * eb <= ((size_t)256 << 20)) return DFFT_OK;  // a cache-resident slab has no placement
+    const bool is_rbuf = p->xd.recvbuf == p->rbuf && p->rbuf;
+    void*      cur = is_rbuf ? p->rbuf : p->buf1;
+    if (!cur || !comm_recv_is_fresh(p->comm, cur)) return DFFT_OK;
+    const size_t bytes = (size_t)p->max_count * eb;
+    DFFT_HIP_TRY(hipDeviceSynchronize());
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return DFFT_OK;
+    }
+    const bool  alone = total_b > 0 && free_b >= total_b / 10 * 9;
+    int         max_tries = 24, pct = alone ? 70 : 25;
+    const char* mt = getenv("DFFT_TUNE_TRIES");
+    if (mt && atoi(mt) > 0) max_tries = atoi(mt);
+    const char* pe = getenv("DFFT_TUNE_MEM_PCT");
+    if (pe && atoi(pe) >= 1 && atoi(pe) <= 90) pct = atoi(pe);
+    const size_t budget = free_b / 100 * (size_t)pct;
+    void*        saved_out = nullptr;
+    if (2 * bytes > budget || hipMalloc(&saved_out, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return DFFT_OK;
+    }
+    if (hipMemcpyAsync(saved_out, p->buf2, bytes, hipMemcpyDeviceToDevice, p->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(saved_out);
+        return DFFT_OK;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipFree(saved_out);
+        return DFFT_OK;
+    }
+    const long long ysub = p->ys / std::max(1, p->ycuts);
+    const size_t    sub = (size_t)p->N[0] * ysub * p->N[2] * eb;
+    auto x_launches = [&](void* cand) -> int {  // exactly what execute_forward queues for t3
+        if (p->part_planes > 0 && p->ycuts > 1) {
+            for (int y = 0; y < p->ycuts; ++y) {
+                const int rc = launch_x(p, (const char*)cand + y * sub, (char*)p->buf2 + y * sub, false, ysub);
+                if (rc) return rc;
+            }
+            return DFFT_OK;
+        }
+        return launch_x(p, cand, p->buf2);
+    };
+    auto probe = [&](void* cand, float* ms_out) -> int {
+        float t[5];
+        for (int i = 0; i < 7; ++i) {
+            if (hipEventRecord(e0, p->stream) != hipSuccess) return fail(DFFT_EHIP, "receive-buffer placement: event");
+            const int rc = x_launches(cand);
+            if (rc) return rc;
+            float ms = 0.f;
+            if (hipEventRecord(e1, p->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                return fail(DFFT_EHIP, "receive-buffer placement: timing");
+            if (i >= 2) t[i - 2] = ms;
+        }
+        std::sort(t, t + 5);
+        *ms_out = t[2];
+        return DFFT_OK;
+    };
+    std::vector<void*> cand(1, cur);
+    p->w_ms.clear();
+    float ms = 0.f;
+    int   rc = probe(cur, &ms);
+    if (rc == DFFT_OK) p->w_ms.push_back(ms);
+    float  lo = ms, hi = ms;
+    size_t used = bytes;
+    while (rc == DFFT_OK && (int)cand.size() < max_tries && used + bytes <= budget) {
+        if (lo < 0.97f * hi) {  // both behaviours seen?  confirm on a second timing of the extremes (dfft_plan_tune)
+            int ilo = 0, ihi = 0;
+            for (int i = 1; i < (int)p->w_ms.size(); ++i) {
+                if (p->w_ms[i] < p->w_ms[ilo]) ilo = i;
+                if (p->w_ms[i] > p->w_ms[ihi]) ihi = i;
+            }
+            for (int idx : {ilo, ihi}) {
+                float again = 0.f;
+                if (probe(cand[idx], &again) == DFFT_OK && again > 0.f) p->w_ms[idx] = std::min(p->w_ms[idx], again);
+            }
+            lo = *std::min_element(p->w_ms.begin(), p->w_ms.end());
+            hi = *std::max_element(p->w_ms.begin(), p->w_ms.end());
+            if (lo < 0.965f * hi) break;
+        }
+        void* nw = nullptr;
+        if (hipMalloc(&nw, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        used += bytes;
+        cand.push_back(nw);
+        rc = probe(nw, &ms);
+        if (rc) break;
+        p->w_ms.push_back(ms);
+        lo = std::min(lo, ms);
+        hi = std::max(hi, ms);
+    }
+    (void)hipStreamSynchronize(p->stream);
+    int best = 0;
+    for (int i = 1; i < (int)p->w_ms.size(); ++i)
+        if (p->w_ms[i] < 0.985f * p->w_ms[best]) best = i;  // a later candidate must be clearly faster
+    for (int i = 1; i < (int)cand.size(); ++i)
+        if (i != best) (void)hipFree(cand[i]);
+    if (best != 0) {
+        // the chosen allocation takes the place of the plan's buffer; bufferDev1 carries the input captured at plan time
+        if (!is_rbuf && hipMemcpyAsync(cand[best], p->in, bytes, hipMemcpyDeviceToDevice, p->stream) != hipSuccess) (void)hipGetLastError();
+        (void)hipStreamSynchronize(p->stream);
+        const int src = comm_recv_swap(p->comm, cur, cand[best]);
+        if (src) rc = src;
+        if (is_rbuf) p->rbuf = cand[best];
+        else p->buf1 = cand[best];
+        p->xd.recvbuf = cand[best];
+    }
+    p->w_kept = best;
+    (void)hipMemcpyAsync(p->buf2, saved_out, bytes, hipMemcpyDeviceToDevice, p->stream);
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(saved_out);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("DFFT_DEBUG")) {
+        fprintf(stderr, "[dfft] receive-buffer placement (rank %d): X pass", p->me);
+        for (float v : p->w_ms) fprintf(stderr, " %.4f", v);
+        fprintf(stderr, " ms, kept candidate %d\n", p->w_kept);
+    }
+    return rc;
+}
+
 extern "C" {
 
 const char* dfft_version(void) { return "dfft-mi355x 0.1 (gfx950)"; }
@@ -1142,13 +1290,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         else p->xd.sendbuf = p->rbuf;                            // in -> X pass -> rbuf (send) -> bufferDev1 -> Y,Z -> out
         p->xd.ycuts = p->ycuts;
     }
-    if (comm) {
-        int rc = comm_register(comm, global_idx, p->xd.recvbuf, p->device, &p->xd.slot);  // nodeDataDev[loc] = bufferDev1, :80
-        if (rc) {
-            dfft_plan_destroy(p);
-            return rc;
-        }
-    }
+    // (the receive buffer is registered with the communicator further down, once its placement has been decided)
     // padded work buffer (dfft_plan_s::wbuf): fused, non-natural pipelines whose rows are whole cache lines and whose three
     // lengths run on the tuned kernels (the run-time-scheduled kernel keeps plain rows).  DFFT_PAD=0 switches it off.
     {
@@ -1207,6 +1349,15 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         p->zy_lazy = !(zl && *zl == '0');  // default on: t0 of 512^3 fp64 1.278 -> 1.163 ms (profiles/r03/experiments/variant_ab.log)
         const char* rf = getenv("DFFT_ZY_INV_ROWS_FIRST");
         p->zy_inv_rows_first = !(rf && *rf == '0');
+    }
+    if (comm) {
+        // placement of the receive buffer (P > 1 twin of dfft_plan_tune), then its registration: after that the peers know the pointer
+        int rc = place_recv_buffer(p);
+        if (rc == DFFT_OK) rc = comm_register(comm, global_idx, p->xd.recvbuf, p->device, &p->xd.slot);  // nodeDataDev[loc] = bufferDev1, :80
+        if (rc) {
+            dfft_plan_destroy(p);
+            return rc;
+        }
     }
     {
         // one-launch t0 (dfft_zy.hip): where the kernel exists and the plan has the unpadded-row hand-over buffer it works on

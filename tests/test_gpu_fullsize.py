@@ -153,10 +153,14 @@ ELEMENTWISE = [
 
 
 @pytest.mark.parametrize("N,P,overlap", ELEMENTWISE)
-def test_fullsize_elementwise_vs_host_fft(gpu, N, P, overlap):
+def test_fullsize_elementwise_vs_host_fft(gpu, N, P, overlap, monkeypatch):
     import numpy as np
     import torch
     from distributedfft_amd import api
+    # P > 1: with the opt-in placement of the receive buffer (dfft_plan.cpp, place_recv_buffer) -- the slabs of these shapes are the
+    # ones it applies to (larger than the Infinity Cache); a few candidates are enough to exercise the swap of the plan's buffer
+    monkeypatch.setenv("DFFT_TUNE_RECV", "1")
+    monkeypatch.setenv("DFFT_TUNE_TRIES", "6")
     n0, n1, n2 = N
     NT = n0 * n1 * n2
     torch.cuda.empty_cache()

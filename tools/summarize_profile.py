@@ -27,10 +27,10 @@ DST = ROOT / "profiles" / ROUND
 
 def short(name: str) -> str:
     m = re.search(r"fft_tiles_kernel<(.*?), dfft::Plan<(\d+), (\d+)[^>]*>, (\d+), (\d+), (-?\d+), (true|false), dfft::(\w+)>", name)
-    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)(?:, (true|false))?(?:, (true|false))?>", name)
+    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)(?:, (true|false))?(?:, (true|false))?(?:, (-?\d+))?>", name)
     if mz:  # t0 as one persistent launch (dfft_zy.hip)
         return (f"zy_chunk_kernel f64 NZ={mz.group(1)} NY={mz.group(2)} dir={mz.group(3)}{' packed' if mz.group(4) == 'true' else ''}"
-                f"{' lazy-publish' if mz.group(5) == 'true' else ''} (one-launch YZ stage)")
+                f"{' lazy-publish' if mz.group(5) == 'true' else ''}{' inverse-rows-first' if mz.group(6) and mz.group(6) != mz.group(3) else ''} (one-launch YZ stage)")
     if not m:
         m2 = re.search(r"fft_generic_kernel<(.*?), (-?\d+)>", name)
         if m2:
@@ -116,7 +116,7 @@ def pmc():
         tot, nexec = 0.0, None
         xn = max([r[-2] for r in out if r[0] == run and "TuneTransposedStore" in r[1]], default=0)  # X launches = executes
         for r in out:
-            zy = r[1].startswith("zy_chunk_kernel") and "dir=1" in r[1]
+            zy = r[1].startswith("zy_chunk_kernel") and "dir=1" in r[1] and "inverse-rows-first" not in r[1]
             if r[0] != run or ((("N=512" not in r[1]) or ("dir=1" not in r[1]) or ("TuneTransposedStore" in r[1])) and not zy):
                 continue
             if zy:
