@@ -249,11 +249,12 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
         trace("comm_register (ipc) enter", reg, c->kind);
         if ((int)c->regs.size() <= reg) c->regs.resize(reg + 1, std::vector<void*>(c->P, nullptr));
         auto share = [&](void* local, std::vector<void*>& out) -> int {
-            // hipIpcGetMemHandle was seen failing with "invalid argument" once in 20 four-process launches on one GPU (round 5,
-            // tools/stall_hunt.py iteration 13: the second pair of plans of a process, i.e. freshly recycled memory, with
-            // HSA_ENABLE_IPC_MODE_LEGACY=0) -- transient on the runtime's side: a few spaced attempts before the error is final.
-            // Every rank still takes part in the broadcasts below either way, so a rank that fails here fails ALONE and its peers
-            // learn of it from the rendezvous (closed connection) instead of waiting for a handle that never comes.
+            // hipIpcGetMemHandle was seen failing with "invalid argument" for freshly recycled memory (round 5, tools/stall_hunt.py: the
+            // second generation of plans of a process, four processes on one device, HSA_ENABLE_IPC_MODE_LEGACY=0).  Repeating the
+            // call did not help in the two launches where it happened with the repeat in place -- what removed the failure is that
+            // pooled communicators never export recycled memory (comm_recv_alloc) -- but a few spaced attempts cost nothing.  A rank
+            // that fails here returns BEFORE the broadcasts below: its peers learn of it from the bounded rendezvous (connection
+            // closed / time-out, DFFT_ECOMM with the reason) instead of waiting for a handle that never comes.
             hipIpcMemHandle_t mine;
             hipError_t        ge = hipErrorUnknown;
             for (int attempt = 0; attempt < 5 && ge != hipSuccess; ++attempt) {
