@@ -80,6 +80,9 @@ __global__ void ipc_sync_kernel(IpcSyncLists L, unsigned long long seq, unsigned
     const int i = threadIdx.x;
     if (i < L.nsig) __hip_atomic_store(L.sig[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     if (i < L.nwait) {
+        // a round that has already timed out makes every later one give up at once: a dead peer costs ONE time limit, not one per
+        // queued round (twelve overlapped executes queue ~120 rounds: round 4's "stall for minutes" behind a rank that had died)
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) return;
         const unsigned long long t0 = wall_clock64();  // 100 MHz
         while (__hip_atomic_load(L.wait[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(16);

@@ -320,3 +320,47 @@ def test_overlapped_pipeline_stress_across_processes(gpu, N, world, parts, ypart
                    {"DFFT_N": "x".join(map(str, N)), "DFFT_OVERLAP_PARTS": parts, "DFFT_OVERLAP_YPARTS": yparts}, timeout=240)
     for r, (o, _) in enumerate(outs):
         assert f"STRESS-OK {r}" in o
+
+
+DEAD_PEER_WORKER = r'''
+import os, sys, time
+import torch
+sys.path.insert(0, os.environ["DFFT_ROOT"])
+from distributedfft_amd import api
+from distributedfft_amd._lib import DfftError
+rank, P = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+N = (64, 64, 32)
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+comm = api.Comm.ipc(P, rank, True)
+mc = api.get_max_data_count(*N, P, rank == P - 1)
+a = torch.ones(mc, dtype=torch.complex128, device=dev)
+b = torch.zeros_like(a)
+p = api.Plan(*N, a, b, comm, rank, P, api.FORWARD, api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP)
+p.execute(api.EXEC_NO_TIMING); p.sync()
+if rank == 1:
+    sys.stdout.flush()
+    os._exit(0)                          # dies without a word, plans and communicator alive
+time.sleep(1.0)
+t0 = time.monotonic()
+try:
+    for _ in range(12):                  # ~60 exchange rounds queued behind a peer that will never answer
+        p.execute(api.EXEC_NO_TIMING)
+    p.sync()
+    print("NO-ERROR")
+except DfftError as e:
+    print("DEAD-PEER", round(time.monotonic() - t0, 1), e.code, str(e)[:160], flush=True)
+sys.stdout.flush()
+os._exit(0)                              # (the collective tear-down would wait for the dead rank as well)
+'''
+
+
+def test_dead_peer_costs_one_time_limit(gpu):
+    """A rank that dies mid-job (round 4's "stalls" were peers waiting behind one): the survivor's queued rounds of the stream-ordered
+    IPC exchange give up after ONE time limit (DFFT_IPC_TIMEOUT_S) -- the first round that times out makes the later ones return at
+    once -- and dfft_plan_sync reports DFFT_ECOMM, instead of one limit per queued round."""
+    outs = _launch(2, [sys.executable, "-c", DEAD_PEER_WORKER], {"DFFT_IPC_TIMEOUT_S": "3"}, timeout=120)
+    line = [l for l in outs[0][0].splitlines() if l.startswith("DEAD-PEER")]
+    assert line, outs[0][0] + outs[0][1][-1500:]
+    _, secs, code, _ = line[0].split(None, 3)
+    assert int(code) == -5 and 2.0 <= float(secs) <= 20.0, line[0]      # DFFT_ECOMM after about one limit, not 60 of them
