@@ -10,7 +10,7 @@ enum { ZY_MAX_PLANES = 4096 };
 
 // -DDFFT_ZY_ROW_PITCH=1 (build-time experiment of the end of round 4, measured and NOT adopted): the row pitch of the hand-over buffer w
 // becomes a launch parameter instead of the compile-time N2, so that a plan whose buffer has padded rows (DFFT_PAD_ROW) can use the
-// one-launch stage.  Meant for BACKWARD single-GPU plans, whose column units read w from HBM at a power-of-two row stride (DESIGN.md
+// one-launch stage.  Meant for BACKWARD single-GPU plans, whose column units read w from HBM at a power-of-two row stride (HISTORY.md
 // section 8-7).  Same digests as the shipped build, no gain: inverse YZ stage of 512^3 fp64 1.42 ms with natural rows, 1.45 with padded
 // ones (profiles/r04/experiments/backward_row_pitch.log).  The default build is byte-identical without it (library d7893003).
 #ifndef DFFT_ZY_ROW_PITCH

@@ -21,7 +21,7 @@
  * receives host arrays: it keeps one device buffer per executor, copies the box in, transforms in place, copies it back.
  * That makes it a functional shim (the reshapes stay on the CPU and every 1-D stage crosses PCIe twice), not the fast path
  * -- the fast path is the slab pipeline behind dfft_plan_create.  Real-to-complex executors are outside the hot path
- * (DESIGN.md section 7): they are declared so that heFFTe's r2c translation unit still compiles, and throw when used.
+ * (DESIGN.md section 8): they are declared so that heFFTe's r2c translation unit still compiles, and throw when used.
  */
 #ifndef HEFFTE_BACKEND_STOCK_FFT_H
 #define HEFFTE_BACKEND_STOCK_FFT_H /* this header replaces heffte_backend_stock.h */
