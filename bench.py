@@ -313,6 +313,12 @@ def main():
                 dog.daemon = True
                 dog.start()
                 try:
+                    # ranks that share a device (only possible with DFFT_BENCH_ALLOW_SHARED_GPU=1, the single-GPU functional tests):
+                    # RCCL refuses duplicate devices -- known from the PCI addresses gathered above, on every rank alike, so
+                    # ncclCommInitRank is not called at all.  (Driving RCCL into that error on purpose worked 50 times out of 50 in
+                    # round 5 but once in round 4 left a rank inside ncclCommInitRank until the watchdog fired, 190 s later.)
+                    if not stub_mode and len(set(idents)) < world:
+                        raise RuntimeError(f"RCCL needs one device per rank: {len(set(idents))} distinct device(s) behind {world} ranks")
                     comm = api.Comm.rccl(uid_bytes, P, rank)
                     info = comm.info()
                     note(f"ncclCommInitRank ok: RCCL reports {info['size']} ranks, this is rank {info['rank']} on device "

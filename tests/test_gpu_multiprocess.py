@@ -239,8 +239,10 @@ def test_heffte_protocol_front_end_multi_process(gpu, world, precision, tol):
 
 
 def test_bench_falls_back_to_ipc_when_rccl_cannot_start(gpu):
-    """Default exchange (RCCL) with two ranks on ONE GPU: RCCL refuses the duplicate device, every rank notices together and
-    the run continues on the stream-ordered IPC communicator -- the report says so."""
+    """Default exchange (RCCL) with two ranks on ONE GPU: RCCL cannot serve duplicate devices -- bench.py knows from the PCI
+    addresses it gathered and does not call ncclCommInitRank at all (round 5; before, RCCL was driven into its error on purpose,
+    which once left a rank inside the call until the 180 s watchdog) -- every rank agrees on the failure and the run continues on
+    the stream-ordered IPC communicator; the report says so."""
     outs = _launch(2, [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--size", "64", "--steps", "3", "--warmup", "1",
                        "--no-cpu-baseline"],
                    {"DFFT_EXCHANGE": "rccl", "NCCL_DEBUG": "WARN",
