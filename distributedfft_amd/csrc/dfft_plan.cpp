@@ -241,8 +241,6 @@ struct dfft_plan_s {
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
     bool                    zy_lazy = false;           // lazy-publish form of the one-launch kernel (un-packed launches; DFFT_ZY_LAZY=0: eager)
     bool                    zy_inv_rows_first = true;  // backward single-GPU plans: inverse stage rows first (DFFT_ZY_INV_ROWS_FIRST=0: columns first)
-    bool                    zy_xcd = false;            // forward single-GPU plans with 256 x 256 planes: the XCD-local form of the stage (dfft_zy.hip)
-    void*                   zy_ring = nullptr;         // ... and its ring of plane slots (8 XCDs x 3 slots)
     int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
     int                     grid_x = 0, grid_y = 0, grid_z = 0;  // DFFT_X_GRID / DFFT_Y_GRID / DFFT_Z_GRID when the plan was created (0 = no cap)
     // Rows of the exchange buffers rotated by rot_elems elements per X plane (RotMap, dfft_kernels.h): P > 1 fused plans whose
@@ -521,14 +519,6 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.ticket_base = p->zy_ticket;
     L.done_base = p->zy_cur * producers;
     if (p->zy_fault > 0 && ++p->zy_launches == (unsigned)p->zy_fault) L.fault = 1;  // test hook: this launch's consumers can never start
-    if (p->zy_xcd && !packed && L.dir > 0 && L.sign > 0 && x0 == 0 && nx == p->xs) {
-        // XCD-local form (dfft_zy.hip, zy_xcd_kernel): its ticket counters live per XCD and reset themselves; the per-plane counters
-        // run on from execute to execute like the other form's (row units per plane = column units per plane = 16 here)
-        unsigned per_plane = zy_units_per_plane(L.n1, L.n2, +1, 0, nullptr);
-        L.ring = p->zy_ring;
-        L.cons_base = p->zy_cur * (per_plane - producers);
-        return check_launch(launch_zy_xcd(L, p->stream), "one-launch YZ stage (XCD-local)");
-    }
     p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.packed, L.nplanes, L.chunk);
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
 }
@@ -1409,14 +1399,6 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                 p->zy_spin_polls = sp && atoll(sp) > 0 ? (unsigned)std::min(atoll(sp), 0xffffffffll) : (4u << 20);
                 const char* fe = getenv("DFFT_ZY_FAULT");
                 p->zy_fault = fe ? atoi(fe) : 0;
-                // XCD-local form of the forward stage: single-GPU forward plans whose planes are 256 x 256 fp64 (1 MiB: three ring slots
-                // per XCD stay resident in its 4 MiB L2 next to the streams).  DFFT_ZY_XCD=0 / 1 switches it off / on.
-                const char* xe = getenv("DFFT_ZY_XCD");
-                if (xe && *xe == '1' && !p->exch && direction == DFFT_FORWARD && zy_xcd_supported(dtype, (int)n1, (int)n2) &&
-                    hipMalloc(&p->zy_ring, zy_ring_bytes((int)n1, (int)n2)) == hipSuccess)
-                    p->zy_xcd = true;
-                else
-                    (void)hipGetLastError();
             } else {
                 (void)hipGetLastError();
             }
@@ -1770,7 +1752,7 @@ int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     snprintf(buf, (size_t)len,
              "pipeline=%s yz_stage=%s%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d x_variant=%s",
              (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
-             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_xcd) ? "-xcd" : ((p->zy_on && fused && p->zy_lazy) ? "-lazy" : ""), nch, cp,
+             (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_lazy) ? "-lazy" : "", nch, cp,
              (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0,
              (p->x_hints & FFT_HINT_HALF_PREFETCH) ? "half-prefetch" : ((p->x_hints & FFT_HINT_EARLY_WAIT) ? "early-wait" : "default"));
     return DFFT_OK;
@@ -1873,7 +1855,6 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     (void)comm_recv_free(plan->comm, plan->rbuf);
     if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
-    if (plan->zy_ring) hipFree(plan->zy_ring);
     if (plan->zy_ctl) hipFree(plan->zy_ctl);
     if (plan->zy_err) hipHostFree(plan->zy_err);
     delete plan;

@@ -33,10 +33,6 @@ struct alignas(128) ZyCtl {
     unsigned error;                // != 0 (ZY_ERR_*): a launch gave up; sticky -- every later launch on this block returns at once
     unsigned pad1[31];
     unsigned done[ZY_MAX_PLANES];  // per plane: producer units that have published their results
-    // XCD-local form of the forward stage (zy_xcd_kernel): per XCD a ticket counter ([x * 32]), and ([8 * 32]) the workgroups of the
-    // running launch that have left; per plane the column units that have loaded their tile out of the plane's ring slot
-    unsigned xcd[9 * 32];
-    unsigned cons[ZY_MAX_PLANES];
 };
 
 struct ZyLaunch {
@@ -60,8 +56,6 @@ struct ZyLaunch {
     long long   pk_plane;     // distance between consecutive X planes inside a block of the packed layout
     RotMap      rot;          // rot != 0: rows of the packed layout are rotated by rot * (plane + a0) elements (mask = N2 - 1)
     const void *twz, *twy;  // N2- and N1-entry twiddle tables (fp64)
-    void*       ring;         // XCD-local form: 8 x ZY_RING_SLOTS plane slots (zy_ring_bytes)
-    unsigned    cons_base;    // XCD-local form: value of ctl->cons[plane] of this launch's planes when it starts
     int         lazy;         // the lazy-publish variant of the kernel (the default; DFFT_ZY_LAZY=0: eager)
     int         fault;        // test hook: the consumers of this launch wait for one producer more than a plane has
     unsigned*   err_host;     // device pointer of a pinned host word: written with ZY_ERR_* when the launch gives up
@@ -74,8 +68,5 @@ long long  zy_grid();
 unsigned   zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers);
 unsigned   zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk);
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream);
-bool       zy_xcd_supported(int dtype, int n1, int n2);
-size_t     zy_ring_bytes(int n1, int n2);
-hipError_t launch_zy_xcd(const ZyLaunch& L, hipStream_t stream);
 
 }  // namespace dfft

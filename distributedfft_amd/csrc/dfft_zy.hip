@@ -423,215 +423,6 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// XCD-local form of the forward stage for planes that fit an XCD's L2 several times over (round 5; fp64 256 x 256 planes = 1 MiB, BASELINE
-// config 2).  tools/l2probe.hip showed what the L2 does (profiles/r05/README.md section 2): a plain store to a line that is RESIDENT updates it
-// in place and a same-XCD sc1 load is then served from the L2, while a plain store that misses first FETCHES the line -- so the Z -> Y
-// hand-over can stay inside one XCD only through a small buffer that never leaves its L2.  Here every plane belongs to ONE XCD
-// (plane p -> XCD p % 8, read from HW_REG_XCC_ID: correct under any workgroup placement, fast under the observed one): the XCD's
-// workgroups take tickets from the XCD's own counter in the order  rows(0) | rows(1) cols(0) | rows(2) cols(1) | ...  (one plane of
-// look-ahead keeps all 32 workgroups busy: 16 + 16 units per step), row units store into a ring of ZY_RING_SLOTS plane slots per XCD
-// with plain stores, column units load from it with sc1 loads and store their results to w with streaming stores.  Two dependencies:
-// a column unit waits for its plane's row units (done[], as in the kernel above); a row unit of plane k waits until every column unit of
-// plane k - SLOTS has LOADED its tile (cons[]) before it overwrites that slot.  Both wait only for smaller tickets of the same XCD, taken
-// by running workgroups: no dead-lock; every spin is bounded like above.  Fabric traffic of the stage: 3 instead of 4 crossings.
-// The XCD counters reset themselves (the last workgroup of an XCD to leave zeroes them), so the host keeps no ticket base for them.
-constexpr int ZY_RING_SLOTS = 3;
-template <class PZ, class PY>
-__global__ void __attribute__((amdgpu_flat_work_group_size(ZyTile<PY, false>::THREADS, ZyTile<PY, false>::THREADS), amdgpu_waves_per_eu(1)))
-zy_xcd_kernel(const double2* src, double2* ring, double2* w, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
-              long long src_plane, long long w_plane, unsigned plane0, unsigned nplanes, unsigned done_base, unsigned cons_base, unsigned* err_host,
-              unsigned spin_polls, unsigned need) {
-    using V = double2;
-    constexpr int CB = ZyTile<PY, false>::CB, THREADS = ZyTile<PY, false>::THREADS;
-    constexpr int N2 = PZ::N, N1 = PY::N, E = PZ::E, TZ = PZ::T, TY = PY::T;
-    static_assert(PZ::E == PY::E && TwTotal<PZ, true>::value <= 16 && TwTotal<PY, true>::value <= 16, "8-point-per-thread plans with register twiddles");
-    constexpr int      GR = THREADS / TZ;
-    constexpr unsigned UZ = N1 / GR, UY = N2 / CB, BB = UZ + UY;
-    constexpr int      ROW_LDS = N2 + N2 / 8;
-    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
-    unsigned* shw = reinterpret_cast<unsigned*>(dfft_smem);
-    V*        lds = reinterpret_cast<V*>(dfft_smem + 64);
-    const int tid = threadIdx.x;
-    const int gz = tid / TZ, jz = tid % TZ, cy = tid % CB, jy = tid / CB;
-    V*        lds_row = lds + gz * ROW_LDS;
-    V         twzr[TwTotal<PZ, true>::value > 0 ? TwTotal<PZ, true>::value : 1], twyr[TwTotal<PY, true>::value > 0 ? TwTotal<PY, true>::value : 1];
-    load_twiddles<V, PZ, 0, +1, true>(twzr, twz, jz);
-    load_twiddles<V, PY, 0, +1, true>(twyr, twy, jy);
-
-    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;  // HW_REG_XCC_ID (id 20), bits 3:0
-    const unsigned K = nplanes > xcc ? (nplanes - xcc + 7u) / 8u : 0u;  // planes of this XCD: plane0 + xcc + 8 k
-    const unsigned total = K ? UZ + K * BB : 0u;
-    unsigned* xt = &ctl->xcd[xcc * 32];  // [0] ticket, [1] workgroups that have arrived, [2] workgroups that have left
-    enum { NONE = 0, ROW = 1, COL = 2 };
-    struct Item {
-        unsigned ticket, kind, k, unit;
-    };
-    auto decode = [&](unsigned t) -> Item {
-        if (t >= total) return Item{t, NONE, 0u, 0u};
-        if (t < UZ) return Item{t, ROW, 0u, t};
-        const unsigned b = (t - UZ) / BB, r = (t - UZ) - b * BB;
-        if (r < UZ) return b + 1 < K ? Item{t, ROW, b + 1, r} : Item{t, NONE, 0u, 0u};
-        return Item{t, COL, b, r - UZ};
-    };
-    auto plane_of = [&](unsigned k) { return plane0 + xcc + 8u * k; };
-    auto slot_of = [&](unsigned k) { return ring + ((size_t)xcc * ZY_RING_SLOTS + k % ZY_RING_SLOTS) * (size_t)N1 * N2; };
-    auto share = [&](unsigned value_of_thread0) -> unsigned {
-        if (tid == 0) shw[0] = value_of_thread0;
-        __syncthreads();
-        const unsigned t = shw[0];
-        __syncthreads();
-        return t;
-    };
-    auto take = [&]() -> unsigned { return tid == 0 ? __hip_atomic_fetch_add(&xt[0], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT) : 0u; };
-    auto raise = [&](unsigned code) {
-        __hip_atomic_store(&ctl->error, code, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
-        __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    auto ready = [&](const Item& it, bool wait) -> bool {
-        if (it.kind == NONE || (it.kind == ROW && it.k < (unsigned)ZY_RING_SLOTS)) return true;
-        if (tid == 0) {
-            const unsigned* word = it.kind == COL ? &ctl->done[plane_of(it.k)] : &ctl->cons[plane_of(it.k - ZY_RING_SLOTS)];
-            const unsigned  base = it.kind == COL ? done_base : cons_base, want = it.kind == COL ? need : UY;
-            unsigned        ok = __hip_atomic_load(word, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - base >= want ? 1u : 0u;
-            if (!ok && wait) {
-                for (unsigned polls = 0;; ++polls) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (__hip_atomic_load(word, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - base >= want) {
-                        ok = 1u;
-                        break;
-                    }
-                    if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) break;
-                    if (polls >= spin_polls) {
-                        raise(ZY_ERR_TIMEOUT);
-                        break;
-                    }
-                }
-            }
-            shw[1] = ok;
-        }
-        __syncthreads();
-        const bool ok = shw[1] != 0u;
-        __syncthreads();
-        return ok;
-    };
-    auto slot_rsrc = [&](unsigned k) { return __builtin_amdgcn_make_buffer_rsrc((void*)slot_of(k), 0, (int)((size_t)N1 * N2 * sizeof(V)), 0x00020000); };
-    auto load_unit = [&](const Item& it, V* d) {
-        if (it.kind == ROW) {
-            const V* ip = src + (long long)plane_of(it.k) * src_plane + (long long)(it.unit * GR + gz) * N2 + jz;
-#pragma unroll
-            for (int k = 0; k < E; ++k) d[k] = gload<true>(ip + TZ * k);
-        } else {
-            const __amdgpu_buffer_rsrc_t rs = slot_rsrc(it.k);
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((jy + TY * k) * N2 + it.unit * CB + cy);
-                d[k] = __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 16u), 0, 16 /* sc1: past this CU's L1, served by the XCD's L2 */));
-            }
-        }
-    };
-    auto finish_unit = [&](const Item& it, V* v) {
-        if (it.kind == ROW) {
-            run_stages<V, PZ, 0, +1, 1, true, true, TW_REG, true>(v, twzr, lds_row, jz, 0);
-            const __amdgpu_buffer_rsrc_t rs = slot_rsrc(it.k);
-#pragma unroll
-            for (int k = 0; k < E; ++k) {
-                const unsigned elem = (unsigned)((it.unit * GR + gz) * N2 + jz + TZ * k);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)(elem * 16u), 0, 0 /* plain: the line stays in this XCD's L2 */);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&ctl->done[plane_of(it.k)], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
-        } else {
-            __syncthreads();
-            // this unit's tile is in registers (the arithmetic below consumes it): the slot may be overwritten once every unit has said so
-            if (tid == 0) __hip_atomic_fetch_add(&ctl->cons[plane_of(it.k)], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
-            run_stages<V, PY, 0, +1, CB, false, false, TW_REG, true>(v, twyr, lds, jy, cy);
-            V* op = w + (long long)plane_of(it.k) * w_plane + (long long)jy * N2 + it.unit * CB + cy;
-#pragma unroll
-            for (int k = 0; k < E; ++k) gstore<true>(op + (long long)(TY * k) * N2, v[k]);
-            __syncthreads();
-        }
-    };
-    V        v[E], vn[E];
-    unsigned first = take();
-    if (tid == 0 && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) first = 0xffffffffu;
-    first = share(first);
-    bool alive = first != 0xffffffffu;
-    Item cur = decode(alive ? first : total), nxt = decode(alive ? share(take()) : total);
-    if (alive && cur.kind != NONE) {
-        alive = ready(cur, true);
-        if (alive) load_unit(cur, v);
-    }
-    while (alive && cur.ticket < total) {
-        const unsigned t2 = take();
-        bool           loaded = false;
-        if (nxt.kind != NONE && ready(nxt, false)) {
-            load_unit(nxt, vn);
-            loaded = true;
-        }
-        if (cur.kind == COL) {  // (a consumed tile must really be in registers before the slot is released)
-#pragma unroll
-            for (int k = 0; k < E; ++k) pin_loaded(v[k]);
-        }
-        if (cur.kind != NONE) finish_unit(cur, v);
-        const Item nn = decode(share(t2));
-        if (nxt.kind != NONE && !loaded) {
-            if (!ready(nxt, true)) {
-                alive = false;
-                break;
-            }
-            load_unit(nxt, v);
-        } else if (loaded) {
-#pragma unroll
-            for (int k = 0; k < E; ++k) v[k] = vn[k];
-        }
-        cur = nxt;
-        nxt = nn;
-    }
-    // The launch's LAST workgroup to leave (counted against the grid size, so independent of where workgroups were placed) puts the XCD
-    // counters back to zero for the next launch -- and checks that every XCD's tickets were all taken: an XCD on which no workgroup of
-    // this launch ever ran (HIP promises nothing about placement) would leave its planes untouched, which must not pass for a result.
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned left = __hip_atomic_fetch_add(&ctl->xcd[8 * 32], 1u, __ATOMIC_ACQ_REL, DFFT_ZY_AGENT) + 1u;
-        if (left == gridDim.x) {
-            bool complete = true;
-            for (unsigned x = 0; x < 8u; ++x) {
-                const unsigned kx = nplanes > x ? (nplanes - x + 7u) / 8u : 0u, tx = kx ? UZ + kx * BB : 0u;
-                if (__hip_atomic_load(&ctl->xcd[x * 32], __ATOMIC_RELAXED, DFFT_ZY_AGENT) < tx) complete = false;
-                __hip_atomic_store(&ctl->xcd[x * 32], 0u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
-            }
-            __hip_atomic_store(&ctl->xcd[8 * 32], 0u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
-            if (!complete && __hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) == 0u) raise(ZY_ERR_DESYNC);
-        }
-    }
-}
-
-template <class PZ, class PY> hipError_t launch_zy_xcd_t(const ZyLaunch& L, hipStream_t stream) {
-    constexpr int    CB = ZyTile<PY, false>::CB, THREADS = ZyTile<PY, false>::THREADS, GR = THREADS / PZ::T;
-    constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * CB * sizeof(double2);
-    constexpr size_t LDS_BYTES = 64 + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
-    auto             kern = zy_xcd_kernel<PZ, PY>;
-    static std::atomic<bool> attr_set[64];
-    static std::mutex        setup_mutex;
-    int                      dev = 0;
-    hipError_t               e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!attr_set[dev].load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> lk(setup_mutex);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set[dev].store(true, std::memory_order_release);
-    }
-    (void)hipGetLastError();
-    hipLaunchKernelGGL(kern, dim3((unsigned)zy_grid()), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.ring, (double2*)L.w, L.ctl,
-                       (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, (unsigned)L.plane0, (unsigned)L.nplanes, L.done_base, L.cons_base,
-                       L.err_host, L.spin_polls, (unsigned)(PY::N / GR) + (L.fault ? 1u : 0u));
-    return hipGetLastError();
-}
-
 template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
     constexpr int    CB = ZyTile<PY, PACK>::CB, THREADS = ZyTile<PY, PACK>::THREADS, GR = THREADS / PZ::T;
     constexpr unsigned UA = DIR > 0 ? (unsigned)(PY::N / GR) : (unsigned)(PZ::N / CB);  // producer units per plane, as in the kernel
@@ -710,16 +501,6 @@ unsigned  zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* prod
 unsigned zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk) {
     const unsigned nchunks = (unsigned)((nplanes + chunk - 1) / chunk);
     return nchunks * (unsigned)chunk * zy_units_per_plane(n1, n2, dir, packed, nullptr) + 2u * (unsigned)zy_grid();
-}
-
-// the XCD-local forward stage: fp64, 256 x 256 planes, un-packed, whole launches of a multiple of 8 planes
-bool zy_xcd_supported(int dtype, int n1, int n2) { return dtype == F64 && n1 == 256 && n2 == 256; }
-size_t zy_ring_bytes(int n1, int n2) { return (size_t)8 * ZY_RING_SLOTS * (size_t)n1 * n2 * sizeof(double2); }
-hipError_t launch_zy_xcd(const ZyLaunch& L, hipStream_t stream) {
-    if (!zy_xcd_supported(L.dtype, L.n1, L.n2) || L.dir <= 0 || L.packed || !L.ring || L.nplanes <= 0 || L.plane0 + L.nplanes > ZY_MAX_PLANES || !L.err_host ||
-        L.spin_polls == 0 || zy_grid() % 8 != 0)
-        return hipErrorInvalidValue;
-    return launch_zy_xcd_t<P256, P256>(L, stream);
 }
 
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {

@@ -338,35 +338,6 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
         assert (outs[mode][1] / n - a).abs().max().item() < 1e-11
 
 
-@pytest.mark.parametrize("N", [(16, 256, 256), (13, 256, 256), (5, 256, 256), (256, 256, 256)])
-def test_xcd_local_t0_is_bit_identical(gpu, N, monkeypatch):
-    """The XCD-local form of the forward YZ stage (dfft_zy.hip, zy_xcd_kernel: every plane belongs to one XCD, the Z -> Y hand-over goes
-    through a ring of three plane slots that stays in that XCD's L2 -- plain stores, sc1 loads, a second dependency that keeps a slot from
-    being overwritten before its column units have loaded it) against two launches per chunk: bit for bit, with plane counts that are and
-    are not multiples of eight, executes queued back to back (the XCD counters reset themselves between launches), and against the oracle."""
-    import torch
-    from distributedfft_amd import api
-    x = so.random_input(N, seed=N[0] + 11)
-    a = torch.from_numpy(x.reshape(-1)).to(gpu)
-    outs = {}
-    for mode in ("two", "xcd"):
-        monkeypatch.setenv("DFFT_T0_ONE_LAUNCH", "0" if mode == "two" else "1")
-        monkeypatch.setenv("DFFT_ZY_XCD", "1" if mode == "xcd" else "0")
-        b = torch.zeros_like(a)
-        p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
-        assert ("yz_stage=one-launch-xcd" in p.describe()) == (mode == "xcd"), p.describe()
-        for _ in range(5):
-            p.execute(api.EXEC_NO_TIMING)
-        p.execute()
-        p.sync()
-        outs[mode] = b.clone()
-        p.destroy()
-    assert torch.equal(outs["two"], outs["xcd"])
-    ref = so.fftn_reference(x, 1)[0]
-    got = outs["xcd"].cpu().numpy().reshape(ref.shape)
-    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-11
-
-
 @pytest.mark.parametrize("direction", [+1, -1])
 def test_one_launch_t0_failure_is_loud_and_recovered(gpu, direction, monkeypatch):
     """A one-launch YZ stage that gives up must never hand back garbage with DFFT_OK.  DFFT_ZY_FAULT=n makes launch n
