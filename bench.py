@@ -129,6 +129,15 @@ def cpu_baseline():
             "sample": f"oracle/slab_oracle.c (scalar C restatement), {n}^3 fp64 forward, 1 thread, {dt:.3f} s"}
 
 
+def is_forward_zy_kernel(name: str) -> bool:
+    """rocprofv3 kernel name of the FORWARD one-launch YZ stage, any variant: zy_chunk_kernel<PZ, PY, DIR = 1, PACK, LAZY[, SIGN = 1]>.
+    (The inverse stage run rows first is <..., 1, false, true, -1>: same structure, other transform -- not t0 of a forward execute.  A
+    template parameter added to the kernel once made this test miss every launch and the bench line's roofline.traffic came out null:
+    tests/test_host_logic.py pins the names.)"""
+    import re
+    return "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*(, 1)?>", name) is not None
+
+
 def library_sha256() -> str | None:
     """sha256 of the native library this process loaded: ties profiles/hbm_traffic.json to the build it was measured on."""
     try:
@@ -193,8 +202,7 @@ def live_traffic(args, nchunks: int):
                     continue
                 if "TuneTransposedStore" in name and ", 1, false" in name:
                     x.append(val)                      # forward X pass (the tuning's probe launches move the same bytes)
-                elif "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*(, 1)?>", name):  # forward one-launch YZ stage (any variant:
-                    # <PZ, PY, DIR = 1, PACK, LAZY, SIGN = 1>; the inverse stage run rows first is <..., 1, false, true, -1>)
+                elif is_forward_zy_kernel(name):
                     zy.append(val)
                 elif ", 1, false, dfft::TuneStreamIn>" in name:
                     rows_.append(val)                  # forward Z rows, one launch per cache chunk

@@ -316,3 +316,19 @@ def test_headline_kernels_do_not_spill():
         assert scratch <= allowed, f"{tag}: {scratch} bytes of scratch"
         # (768-point Y axis: 12 points + 12 prefetched per thread, five stages' index arithmetic: the lazy kernels sit at 244-250)
         assert vgpr <= (224 if "lazy" in tag and " Y=768 " not in tag else 256), f"{tag}: {vgpr} registers"
+
+
+def test_bench_recognises_the_forward_yz_stage_in_rocprof_names():
+    """bench.py's in-run counter pass finds t0's launches by kernel name (roofline.traffic of the dominant kernel).  The names carry the
+    kernel's template arguments; when the stage gained a parameter in round 5 the pattern missed them all and the traffic came out null."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", ROOT / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    pre = "void dfft::(anonymous namespace)::zy_chunk_kernel<dfft::Plan<512, 8, 8, 8, 8>, dfft::Plan<512, 8, 8, 8, 8>, "
+    post = ">(HIP_vector_type<double, 2u> const*, HIP_vector_type<double, 2u>*)"
+    for args, want in (("1, false, true, 1", True), ("1, true, true, 1", True), ("1, false, false, 1", True), ("1, false, true", True),
+                       ("1, false, true, -1", False),      # the inverse stage run rows first
+                       ("-1, false, true, -1", False), ("-1, true, true, -1", False)):
+        assert b.is_forward_zy_kernel(pre + args + post) is want, args
+    assert not b.is_forward_zy_kernel("void dfft::fft_tiles_kernel<HIP_vector_type<double, 2u>, dfft::Plan<512, 8, 8, 8, 8>, 8, 1, 1, false, dfft::TuneTransposedStore>(...)")
