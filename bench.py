@@ -416,6 +416,7 @@ def main():
     # P > 1: the un-overlapped plan is both the diagnostic (full t2) and the referee -- the overlapped pipeline must
     # reproduce its result bit for bit on every rank, otherwise the timed loop falls back to it
     plan_s, b2, overlap_note, pipeline_probe_ms, referee_same = None, None, None, None, None
+    referee_forms_note, referee_bits = None, None
     if overlap:
         try:
             b2 = torch.zeros(max_count, dtype=cdt, device=dev)
@@ -427,9 +428,25 @@ def main():
             plan_s.execute(api.EXEC_ASYNC)
             plan_s.sync()
             barrier()
-            same_t = torch.tensor([1.0 if torch.equal(b2[:count], b[:count]) else 0.0], dtype=torch.float64)
+            same_bits = torch.equal(b2[:count], b[:count])
+            # The two plans normally run the same kernels and must agree bit for bit.  Where they run different FORMS of the YZ stage
+            # (dfft_plan_describe: the lazy one-launch stage agrees with two launches per chunk only to the last bit or two, by
+            # construction) bit-equality cannot hold; a race in the overlapped pipeline corrupts whole blocks, so 1e-13 of max|X|
+            # still catches what the referee is there for.
+            forms_differ = (not stub_mode and hasattr(plan, "describe")
+                            and plan.describe().split("yz_stage=")[1].split()[0] != plan_s.describe().split("yz_stage=")[1].split()[0])
+            close = same_bits
+            if not same_bits and forms_differ:
+                scale_r = b2[:count].abs().max().item()
+                referee_rel = ((b2[:count] - b[:count]).abs().max().item() / scale_r) if scale_r > 0 else float("inf")
+                close = referee_rel <= 1e-13
+                referee_forms_note = (f"the serial and the overlapped plan run different forms of the YZ stage ({plan_s.describe().split('yz_stage=')[1].split()[0]} / "
+                                      f"{plan.describe().split('yz_stage=')[1].split()[0]}), which agree to the last bit or two by construction: compared to "
+                                      f"1e-13 of max|X| instead of bit for bit (max relative difference on this rank {referee_rel:.2e})")
+            same_t = torch.tensor([1.0 if close else 0.0, 1.0 if same_bits else 0.0], dtype=torch.float64)
             dist.all_reduce(same_t, op=dist.ReduceOp.MIN)
-            referee_same = same_t.item() == 1.0
+            referee_same = same_t[0].item() == 1.0
+            referee_bits = same_t[1].item() == 1.0
             if not referee_same:
                 overlap_note = "overlapped result differed from the serial pipeline: timed the serial pipeline instead"
             elif not stub_mode:
@@ -699,13 +716,19 @@ def main():
                     "t0": round(float(serial_stage[0]) * 1e3, 4), "t1": round(float(serial_stage[1]) * 1e3, 4),
                     "t2": round(float(serial_stage[2]) * 1e3, 4), "t3": round(float(serial_stage[3]) * 1e3, 4)}
                 result["overlap_result_bit_identical"] = same
+                if referee_forms_note is not None:
+                    result["overlap_result_within_1e-13"] = referee_same
             elif referee_same is not None:
-                result["overlap_result_bit_identical"] = referee_same  # the referee's verdict before the fallback
+                result["overlap_result_bit_identical"] = referee_bits  # the referee's findings before the fallback
+                if referee_forms_note is not None:
+                    result["overlap_result_within_1e-13"] = referee_same
             result["pipeline"] = "overlapped" if overlap else "serial"
             if comm_fallback is not None:
                 result["exchange_fallback"] = comm_fallback
             if overlap_note is not None:
                 result["overlap_fallback"] = overlap_note
+            if referee_forms_note is not None:
+                result["overlap_referee"] = referee_forms_note
             if pipeline_probe_ms is not None:
                 result["pipeline_probe_ms_per_step"] = pipeline_probe_ms
         if P == 1 and not args.no_cpu_baseline:
