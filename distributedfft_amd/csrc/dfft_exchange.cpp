@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -31,20 +32,25 @@ struct dfft_comm_s {
     std::condition_variable cv;
     int                     arrived = 0;
     unsigned long           generation = 0;
+    bool                    barrier_broken = false;  // a device thread gave up waiting in comm_thread_barrier: every later barrier fails at once
     int                     agree_in = 0;       // comm_agree_max: the devices' contributions of the round in progress
     int*                    agree_dev = nullptr;  // rccl: two device words for the one-element all-reduce
     // IPC communicators: receive buffers and their registrations (the peers' mappings, the flag words) are kept for the life of the
     // communicator and handed to the next plan that asks with the same key (comm_recv_alloc) -- see there for why
     struct PoolEntry {
-        std::string key;
-        void*       buf;
-        size_t      bytes;
-        int         reg;
-        bool        used;
+        std::string   key;  // role of the buffer in a plan ("b1", "nat", "rb"): any unused entry of the role that is large enough is reused
+        void*         buf;
+        size_t        bytes;
+        int           reg;
+        bool          used;
+        unsigned long stamp;  // pool_clock when the entry was last handed out or handed back (eviction order: least recent first)
     };
     std::vector<PoolEntry>       pool;
     std::map<void*, std::string> pending;  // fresh allocations of comm_recv_alloc that are not registered yet
     bool                         pooled = false;
+    size_t                       pool_budget = 0;  // bytes the pool may hold before idle entries are evicted (DFFT_IPC_POOL_MB; 0 = no limit)
+    unsigned long                pool_clock = 0;
+    std::vector<std::pair<uintptr_t, size_t>> retired;  // address ranges that were exported once and freed: never exported again
     // Receive buffers by registration: every plan registers its receive buffer(s) in creation order, and plans are created
     // in the same order on every device thread / process, so registration r of device q is the buffer device q's r-th
     // exchange descriptor receives into (the reference shares ONE node_data[] between its forward and backward plan and
@@ -117,14 +123,24 @@ int comm_size(dfft_comm_t c) { return c->P; }
 int comm_thread_barrier(dfft_comm_t c) {
     if (c->kind == 2) return dfft_boot_barrier();  // processes instead of threads: the TCP rendezvous is the barrier
     if (c->kind != 0 || c->P <= 1) return DFFT_OK;
+    // bounded: a device thread that never arrives -- it returned early from a collective call, or died -- must not hold
+    // the others for ever.  DFFT_BOOT_TIMEOUT_S (default 180 s), the bound of the inter-process rendezvous; sticky once it has struck.
+    static const double limit_s = [] {
+        const char* e = std::getenv("DFFT_BOOT_TIMEOUT_S");
+        return e && atof(e) > 0 ? atof(e) : 180.0;
+    }();
     std::unique_lock<std::mutex> lk(c->m);
+    if (c->barrier_broken) return fail(DFFT_ECOMM, "comm_thread_barrier: an earlier barrier of this communicator timed out");
     const unsigned long gen = c->generation;
     if (++c->arrived == c->P) {
         c->arrived = 0;
         ++c->generation;
         c->cv.notify_all();
-    } else {
-        c->cv.wait(lk, [&] { return c->generation != gen; });
+    } else if (!c->cv.wait_for(lk, std::chrono::duration<double>(limit_s), [&] { return c->generation != gen || c->barrier_broken; }) || c->barrier_broken) {
+        c->barrier_broken = true;
+        c->cv.notify_all();
+        return fail(DFFT_ECOMM, "comm_thread_barrier: not every device thread of the communicator arrived within " + std::to_string((int)limit_s) +
+                                    " s (DFFT_BOOT_TIMEOUT_S): a collective call was skipped on one of them");
     }
     return DFFT_OK;
 }
@@ -140,20 +156,116 @@ int comm_thread_barrier(dfft_comm_t c) {
 // role) gets them -- no handle is created twice for one piece of memory, and re-planning costs no rendezvous round trips.  Plans
 // are created and destroyed in the same order on every rank, so every rank makes the same choice.  DFFT_IPC_POOL=0 restores the
 // export / unmap / free cycle per plan (A/B switch).
-int comm_recv_alloc(dfft_comm_t c, const std::string& key, size_t bytes, void** out) {
-    *out = nullptr;
-    if (c && c->pooled) {
-        for (auto& e : c->pool) {
-            if (e.used || e.key != key) continue;
-            if (e.bytes < bytes) return fail(DFFT_ECOMM, "comm_recv_alloc: pooled buffer '" + key + "' is smaller than requested");
-            e.used = true;
-            *out = e.buf;
-            trace("comm_recv_alloc: pooled buffer reused", e.reg, (long long)bytes);
-            return DFFT_OK;
+//
+// Round 6: the pool is bounded and its hand-overs are checked.
+//  * An idle entry serves ANY later plan that needs a buffer of the same role and at most its size (best fit), not only a plan of the
+//    very same shape: an application that re-plans over many shapes on one communicator keeps as many buffers as it has plans alive at
+//    once, sized for the largest of them, instead of one or two slabs per shape.  Sizes are requested rank-symmetrically (the plan
+//    asks for the larger of the last / not-last device's count), so every rank finds the same entry.
+//  * DFFT_IPC_POOL_MB (default: half of the device's memory) bounds what the pool holds: before a NEW buffer is allocated, idle
+//    entries are evicted least-recently-used first until pool + request fit (entries in use are never touched -- the bound is on
+//    the idle part).  Eviction is collective and deterministic (same pool, same order on every rank): peers unmap, rendezvous, the
+//    owner frees.  The address range of an evicted buffer is remembered and never exported again (a fresh allocation that lands on
+//    it is set aside and another one is taken): re-exporting recycled memory is exactly what the pool exists to avoid.
+//  * Every reuse is a small rendezvous: all ranks must have picked the same registration and issued the same number of exchange
+//    rounds on it (one all-reduce over the TCP rendezvous) -- which is also the hand-shake that every peer is done with the buffer's
+//    previous plan before the new plan's plan-time input copy lands in it.
+namespace {
+int pool_evict(dfft_comm_t c, size_t idx) {
+    const dfft_comm_s::PoolEntry e = c->pool[idx];
+    trace("comm pool: evicting an idle entry", e.reg, (long long)e.bytes);
+    (void)hipDeviceSynchronize();
+    unsigned long long* own_flags = nullptr;
+    for (int q = 0; q < c->P; ++q) {
+        if (e.reg < (int)c->regs.size()) {
+            void*& r = c->regs[e.reg][q];
+            if (r && q != c->rank) (void)hipIpcCloseMemHandle(r);
+            r = nullptr;
+        }
+        if (e.reg < (int)c->flag_regs.size()) {
+            unsigned long long*& f = c->flag_regs[e.reg][q];
+            if (f && q != c->rank) (void)hipIpcCloseMemHandle(f);
+            if (q == c->rank) own_flags = f;
+            f = nullptr;
         }
     }
-    DFFT_HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
-    if (c && c->pooled) c->pending[*out] = key + "#" + std::to_string(bytes);
+    (void)hipGetLastError();
+    const int rc = dfft_boot_barrier();  // every peer has unmapped: only now may the owners free
+    if (own_flags) (void)hipFree(own_flags);
+    (void)hipFree(e.buf);
+    c->retired.emplace_back((uintptr_t)e.buf, e.bytes);
+    c->pool.erase(c->pool.begin() + (long)idx);
+    return rc;
+}
+bool pool_overlaps_retired(dfft_comm_t c, void* p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    for (const auto& r : c->retired)
+        if (a < r.first + r.second && r.first < a + bytes) return true;
+    return false;
+}
+std::string pool_role(const std::string& key) {
+    const size_t cut = key.rfind(':');
+    return cut == std::string::npos ? key : key.substr(cut + 1);
+}
+}  // namespace
+
+int comm_recv_alloc(dfft_comm_t c, const std::string& key, size_t bytes, void** out) {
+    *out = nullptr;
+    if (!c || !c->pooled) {
+        DFFT_HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+        return DFFT_OK;
+    }
+    const std::string role = pool_role(key);
+    int best = -1;
+    for (int i = 0; i < (int)c->pool.size(); ++i) {
+        const auto& e = c->pool[i];
+        if (e.used || e.key != role || e.bytes < bytes) continue;
+        if (best < 0 || e.bytes < c->pool[best].bytes) best = i;  // best fit; ties: the older registration
+    }
+    if (best >= 0) {
+        auto& e = c->pool[best];
+        // hand-shake: same registration, same number of rounds issued on it, on every rank
+        const double sq = e.reg < (int)c->seq.size() ? (double)c->seq[e.reg] : 0.0;
+        double       v[4] = {(double)e.reg, -(double)e.reg, sq, -sq};
+        const int    rc = dfft_boot_allreduce_max(v, 4);
+        if (rc) return rc;
+        if (v[0] != -v[1] || v[2] != -v[3])
+            return fail(DFFT_ECOMM, "comm_recv_alloc: the ranks of this communicator disagree about the pooled receive buffer a new plan takes over (registration " +
+                                        std::to_string(e.reg) + ": plans must be created and destroyed in the same order on every rank)");
+        e.used = true;
+        e.stamp = ++c->pool_clock;
+        *out = e.buf;
+        trace("comm_recv_alloc: pooled buffer reused", e.reg, (long long)bytes);
+        return DFFT_OK;
+    }
+    if (c->pool_budget > 0) {
+        for (;;) {
+            size_t held = 0;
+            for (const auto& e : c->pool) held += e.bytes;
+            if (held + bytes <= c->pool_budget) break;
+            int lru = -1;
+            for (int i = 0; i < (int)c->pool.size(); ++i)
+                if (!c->pool[i].used && (lru < 0 || c->pool[i].stamp < c->pool[lru].stamp)) lru = i;
+            if (lru < 0) break;  // everything the pool holds is in use: the bound is on the idle part
+            const int rc = pool_evict(c, (size_t)lru);
+            if (rc) return rc;
+        }
+    }
+    std::vector<void*> aside;
+    hipError_t         e = hipSuccess;
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        e = hipMalloc(out, bytes ? bytes : 16);
+        if (e != hipSuccess || !pool_overlaps_retired(c, *out, bytes ? bytes : 16)) break;
+        aside.push_back(*out);  // lands on memory that was exported before: keep it out of the way and take another
+        *out = nullptr;
+    }
+    for (void* a : aside) (void)hipFree(a);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DFFT_EHIP, std::string("comm_recv_alloc: ") + hipGetErrorString(e));
+    }
+    if (!*out) return fail(DFFT_EHIP, "comm_recv_alloc: every fresh allocation landed on an address range this communicator has exported before");
+    c->pending[*out] = role + "#" + std::to_string(bytes);
     return DFFT_OK;
 }
 // Is `buf` an allocation of comm_recv_alloc that no peer knows yet (not registered, not from the pool)?  Only such a buffer may still
@@ -179,6 +291,7 @@ int comm_recv_free(dfft_comm_t c, void* buf) {
         for (auto& e : c->pool)
             if (e.buf == buf) {
                 e.used = false;  // stays allocated, exported and mapped by the peers
+                e.stamp = ++c->pool_clock;
                 return DFFT_OK;
             }
         c->pending.erase(buf);
@@ -310,7 +423,7 @@ int comm_register(dfft_comm_t c, int me, void* recvbuf, int device, int* reg_out
             auto it = c->pending.find(recvbuf);
             if (it != c->pending.end()) {
                 const size_t      cut = it->second.rfind('#');
-                dfft_comm_s::PoolEntry pe{it->second.substr(0, cut), recvbuf, (size_t)std::stoull(it->second.substr(cut + 1)), reg, true};
+                dfft_comm_s::PoolEntry pe{it->second.substr(0, cut), recvbuf, (size_t)std::stoull(it->second.substr(cut + 1)), reg, true, ++c->pool_clock};
                 c->pool.push_back(pe);
                 c->pending.erase(it);
             }
@@ -701,6 +814,14 @@ int dfft_comm_create_ipc(int total_devices, int global_idx, int async_exchange, 
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return fail(DFFT_ENOGPU, "dfft_comm_create_ipc: no HIP device");
+    }
+    {
+        // what the pool of receive buffers may hold before idle entries are evicted: DFFT_IPC_POOL_MB, default half of the device's memory
+        const char* mb = getenv("DFFT_IPC_POOL_MB");
+        size_t      free_b = 0, total_b = 0;
+        if (mb && atoll(mb) >= 0) c->pool_budget = (size_t)atoll(mb) << 20;
+        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->pool_budget = total_b / 2;
+        else (void)hipGetLastError();
     }
     if (c->kind == 3) {
         void* e = nullptr;

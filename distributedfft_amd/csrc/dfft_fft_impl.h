@@ -337,7 +337,28 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
         run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
         return;
 #endif
-        if constexpr (PH == 1) {
+        // Thread-local exchange (round 6).  The scatter after stage S sends the result (jq, r) to position
+        //     p = (jq / NS) NS R + jq mod NS + r NS,         jq = j + q T,
+        // and position p is read back by thread p mod T as its point p / T.  When T divides NS every term but j is a multiple of
+        // T: p mod T = j -- the thread reads back exactly what it wrote, the "exchange" is a renaming of its own registers
+        //     v'[(qT / NS)(NS / T) R + (qT mod NS) / T + r NS / T] = v[q + r B]
+        // (compile-time indices: no instruction at all), and the LDS round trip with its two barriers disappears.  True for the
+        // stages whose remaining radix product fits the E points of a thread: the exchange in front of the last stage of 1024 = 8 8 8 2
+        // on 16 x 64 threads (config 4's X axis, the halves of config 5's DIF-split 2048-point Y axis), of 768 = 4 4 4 4 3 on 12 x 64
+        // (config 4's Y axis), 1536 = 8 8 8 3, the one-wavefront rows of 2048 points (32 x 64).  Same values in the same order of
+        // operations: bit-identical results.  -DDFFT_LOCAL_EXCHANGE=0 builds the LDS form (A/B).
+#ifndef DFFT_LOCAL_EXCHANGE
+#define DFFT_LOCAL_EXCHANGE 1
+#endif
+        if constexpr (DFFT_LOCAL_EXCHANGE && NS % T == 0) {
+            V t[E];
+#pragma unroll
+            for (int q = 0; q < B; ++q)
+#pragma unroll
+                for (int r = 0; r < R; ++r) t[((q * T) / NS) * (NS / T) * R + ((q * T) % NS) / T + r * (NS / T)] = v[q + r * B];
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = t[k];
+        } else if constexpr (PH == 1) {
             if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
             // Padded rows (one element per 8): where the step between a thread's accesses is a multiple of 8 elements the
             // padded index is affine in the access number -- written out that way so that the accesses become ONE address

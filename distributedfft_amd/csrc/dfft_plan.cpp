@@ -232,6 +232,9 @@ struct dfft_plan_s {
     // t0 as one persistent launch (dfft_zy.hip) instead of two launches per cache chunk: single-GPU fused plans in fp64 whose Y and
     // Z lengths the kernel is built for.  zy_ctl: its control block (ticket counter, per-plane counters, error word).
     ZyCtl*                  zy_ctl = nullptr;
+    // the plan's shape and flags select the one-launch stage (whether or not THIS device could allocate its control block): the same
+    // on every device of a communicator, so it -- and not zy_ctl -- decides who takes part in the agreement round of dfft_execute
+    bool                    zy_eligible = false;
     unsigned*               zy_err = nullptr;   // pinned host word the kernel writes ZY_ERR_* to when it gives up (read without a copy)
     unsigned                zy_spin_polls = 0;  // bound of a consumer unit's wait (polls; DFFT_ZY_SPIN_POLLS)
     int                     zy_fault = 0;       // DFFT_ZY_FAULT=n (test hook): launch number n of the stage waits for producers that never come
@@ -785,7 +788,9 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     // Y columns (in place on the intermediate, or unpacking the receive buffer into it), then Z rows into the result: one launch
     // single-GPU plans with a hand-over buffer: rows first (dfft_zy.hip, SIGN) -- Z rows hand-over buffer -> result buffer, Y columns in place
     // on the result buffer; the transform is the same, its strided side moves from HBM reads to the cache-resident chunk
-    if (one_launch && p->zy_inv_rows_first && xw && p->zy_lazy) DFFT_TRY(launch_zy_stage(p, p->wbuf, ybuf, n1 * n2, nullptr, nullptr, false, 0, p->xs, +1));
+    // (the kernel's row-producing source path reads rows n2 apart: a hand-over buffer with padded ROWS -- the -DDFFT_ZY_ROW_PITCH=1 build
+    // only -- keeps columns first)
+    if (one_launch && p->zy_inv_rows_first && xw && p->zy_lazy && p->wl.pitch == n2) DFFT_TRY(launch_zy_stage(p, p->wbuf, ybuf, n1 * n2, nullptr, nullptr, false, 0, p->xs, +1));
     else if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, fused ? ydst : ybuf, yl.plane, ybuf, y_unpacks ? p->buf1 : nullptr, y_unpacks, 0, p->xs));
     for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
@@ -814,6 +819,12 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
 // inside the pipeline), config 4's rank at P = 8: 128 candidates within 3 % of each other.  A gain in one shape, plan-time cost and a
 // transient footprint of many slabs in all of them, on a path that has never run on real links: OPT-IN, DFFT_TUNE_RECV=1 (at most
 // DFFT_TUNE_TRIES, default 24, candidates).
+// Bytes of a buffer that is (or may be) registered as a receive buffer: the larger of the last / not-last device's element count, so
+// that every rank of a communicator asks its pool for the same size (comm_recv_alloc: pooled entries are matched by size).
+static size_t recv_buffer_bytes(const dfft_plan_s* p) {
+    const long long a = dfft_max_count(p->N[0], p->N[1], p->N[2], p->P, 0), b = dfft_max_count(p->N[0], p->N[1], p->N[2], p->P, 1);
+    return (size_t)std::max(a, b) * elem_bytes(p->dtype);
+}
 static int place_recv_buffer(dfft_plan_s* p) {
     const char* te = getenv("DFFT_TUNE_RECV");
     if (!(te && *te == '1')) return DFFT_OK;
@@ -906,7 +917,7 @@ static int place_recv_buffer(dfft_plan_s* p) {
             if (lo < 0.965f * hi) break;
         }
         void* nw = nullptr;
-        if (hipMalloc(&nw, bytes) != hipSuccess) {
+        if (hipMalloc(&nw, recv_buffer_bytes(p)) != hipSuccess) {  // (the size the pool was asked for: the candidate may take the buffer's place)
             (void)hipGetLastError();
             break;
         }
@@ -1205,7 +1216,8 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     // buffers that are (or may be) registered as receive buffers come from the communicator (pooled per key by IPC communicators)
     const std::string rkey = std::to_string(n0) + "x" + std::to_string(n1) + "x" + std::to_string(n2) + ":" + std::to_string(dtype) + ":" +
                              std::to_string(total_devices);
-    if (e == hipSuccess && comm_recv_alloc(comm, rkey + ":b1", bytes, &p->buf1) != DFFT_OK) e = hipErrorOutOfMemory;
+    const size_t rbytes = recv_buffer_bytes(p);  // rank-symmetric (>= bytes)
+    if (e == hipSuccess && comm_recv_alloc(comm, rkey + ":b1", rbytes, &p->buf1) != DFFT_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     // :77 input captured at plan time.  A device-to-device hipMemcpy on the null stream may return before the copy has run and is not
     // ordered with this plan's (non-blocking) stream -- and bufferDev1 is the RECEIVE buffer of the exchange: a copy that ran late
@@ -1266,7 +1278,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (natural && p->exch) {
         // natural-order plans re-slab twice (X->Y for the X pass, Y->X to return to the caller's layout); the second
         // exchange receives the packed [src][xs][yl_src][N2] blocks into a buffer of its own and uses the other slot
-        if (comm_recv_alloc(comm, rkey + ":nat", bytes, &p->rbuf) != DFFT_OK) {
+        if (comm_recv_alloc(comm, rkey + ":nat", rbytes, &p->rbuf) != DFFT_OK) {
             dfft_plan_destroy(p);
             return fail(DFFT_EHIP, "dfft_plan_create: no memory for the second receive buffer");
         }
@@ -1282,7 +1294,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
     if (p->part_planes > 0) {
         // overlap mode: parts arrive while later planes are still being transformed in bufferDev1, so the exchange
         // needs a receive buffer of its own (one more slab in HBM; 288 GB makes that a non-issue)
-        if (comm_recv_alloc(comm, rkey + ":rb", bytes, &p->rbuf) != DFFT_OK) {
+        if (comm_recv_alloc(comm, rkey + ":rb", rbytes, &p->rbuf) != DFFT_OK) {
             dfft_plan_destroy(p);
             return fail(DFFT_EHIP, "dfft_plan_create: no memory for the receive buffer of the overlapped exchange");
         }
@@ -1386,6 +1398,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512 && ysub % 64 == 0) || (oe && !strcmp(oe, "all"));
         if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
+            p->zy_eligible = true;
             // zeroed ON THE PLAN'S STREAM and waited for: a memset on the null stream is asynchronous to the host and not ordered
             // with a non-blocking stream -- the first launch could start on uninitialised counters (seen once in the full test
             // suite, on recycled memory)
@@ -1517,31 +1530,37 @@ int dfft_execute(dfft_plan_t plan, unsigned exec_flags) {
     const bool zy_used = plan->zy_on;
     if (plan->P > 1) trace("dfft_execute", plan->direction, exec_flags);
     int        rc = run();
-    if (rc) return rc;
     // host-synchronised executes have drained the stream (the reference-named wrapper always executes this way): a one-launch YZ
     // stage that gave up is seen here, before any timing is printed or any result used.  Where the pipeline has not written its own
     // input -- fused single-GPU plans that read `in` or bufferDev1 and work in the hand-over buffer -- the transform is simply run
     // again on two launches per chunk (zy_check has switched the stage off); otherwise the failure is the return code.
-    if (sync && plan->exch && plan->zy_ctl && plan->direction == DFFT_FORWARD) {
+    // Who takes part in the agreement round is decided by rank-symmetric data only: the shape / flag predicate that selects
+    // the stage (zy_eligible), not this device's allocation result or history -- and a device whose run() failed locally still enters
+    // the round (contributing "failed"), so its peers are never left waiting in a collective one rank has skipped.
+    const bool agree = sync && plan->exch && plan->zy_eligible && plan->direction == DFFT_FORWARD;
+    if (rc && !agree) return rc;
+    if (agree) {
         // (backward plans run the stage AFTER their exchange: a failure there spoils only the failing rank's own result, which that
         // rank reports itself below -- no collective needed, none paid)
         // P > 1: the failure is rank-local knowledge, but the exchange has already shipped this rank's invalid data to every peer.
-        // Every device of the communicator learns of it here (every plan of the communicator that was BUILT with the stage takes
-        // part, whether its own stage is still on or not -- the condition must not depend on a rank's own history), returns an error
-        // and continues on the two-launch stage, so no rank ever returns DFFT_OK for an execute that any rank knows to be invalid.
-        int mine = zrc0 ? 1 : 0;
+        // Every device of the communicator learns of it here, returns an error and continues on the two-launch stage, so no rank
+        // ever returns DFFT_OK for an execute that any rank knows to be invalid.
+        const int   run_rc = rc;
+        std::string run_msg = run_rc ? g_last_error : std::string();
+        int         mine = (zrc0 || run_rc) ? 1 : 0;
         if (!mine && zy_used) {
             mine = zy_check(plan) ? 1 : 0;
             if (mine) zmsg0 = g_last_error;
         }
         int any = 0;
         rc = comm_agree_max(plan->comm, plan->me, mine, plan->stream, &any);
+        if (run_rc) return fail(run_rc, run_msg);  // this device's own failure is its return code, whatever the round said
         if (rc) return rc;
         if (any) {
             plan->zy_on = false;
             return mine ? fail(DFFT_EHIP, zmsg0)
-                        : fail(DFFT_EHIP, "the one-launch YZ stage gave up on another device of this communicator: the results of this execute are invalid on "
-                                          "every device; later executes use the two-launch stage");
+                        : fail(DFFT_EHIP, "the one-launch YZ stage gave up (or the execute failed) on another device of this communicator: the results of this "
+                                          "execute are invalid on every device; later executes use the two-launch stage");
         }
     } else if (sync && zy_used) {
         rc = zy_check(plan);

@@ -58,15 +58,12 @@ inline longInt64 getMaxDataCount(int n0, int n1, int n2, int totalDevCount, bool
     return dfft_max_count(n0, n1, n2, totalDevCount, isLastDevice ? 1 : 0);
 }
 
-// fft_mpi_init (fft_mpi_3d_api.cpp:3-39): device-count fix-up, per-device element counts, exchange set-up.
+// getProperDeviceNum (fft_mpi_3d_api.h:77, fft_mpi_3d_api.cpp:232-272): shrink the device count until every device owns at least one
+// X-plane of a ceil split (N0 % P != 0), hand the devices out to the ranks, print the reference's lines.
 // Environment: DFFT_VIRTUAL_DEVICES=1 lets GPU_COUNT exceed the visible device count (devices are then shared
 // round-robin exactly as the reference driver's hipSetDevice(globalIdx % devCount), fftSpeed3d_c2c.cpp:53).
-inline void fft_mpi_init(const longInt64* N, int iniDeviceNumInNode, MPI_Comm comm, int& newDeviceCount,
-                         int& newDeviceCountInNode, longInt64 dataCountInNode[]) {
-    using namespace dfft_api_detail;
-    int mpi_size, mpi_rank;
-    MPI_CHECK(MPI_Comm_size(comm, &mpi_size));
-    MPI_CHECK(MPI_Comm_rank(comm, &mpi_rank));
+inline void getProperDeviceNum(const longInt64* N, int iniDeviceNumInNode, int mpi_size, int mpi_rank, int& newDeviceCount,
+                               int& newDeviceCountInNode) {
     int         real = dfft_device_count();
     const char* virt = getenv("DFFT_VIRTUAL_DEVICES");
     const bool  allow_virtual = virt && atoi(virt) != 0;
@@ -74,14 +71,34 @@ inline void fft_mpi_init(const longInt64* N, int iniDeviceNumInNode, MPI_Comm co
         printf("The number of GPUs in rank %d is less than %d, so it will be set to %d (equal to your real device count).\n",
                mpi_rank, iniDeviceNumInNode, real);  // fft_mpi_3d_api.cpp:237
     }
+    // (a distribution that leaves this rank without a device is the reference's "could not support this distribution of data,
+    // exit!!", :265-268: DFFT_CHECK prints the library's message for it and exits the same way)
     DFFT_CHECK(dfft_proper_device_count(N, iniDeviceNumInNode, mpi_size, mpi_rank, allow_virtual ? -1 : real,
                                         &newDeviceCount, &newDeviceCountInNode));
     printf("allocate %d devices to node %d\n", newDeviceCountInNode, mpi_rank);  // :270
-    const int first = first_dev_of_rank(newDeviceCount, mpi_size, mpi_rank);
-    for (int i = 0; i < newDeviceCountInNode; ++i) {
-        dataCountInNode[i] = dfft_local_count(N, newDeviceCount, first + i);
-        printf("data count in device %d of node %d: %lld\n", i, mpi_rank, dataCountInNode[i]);  // :285
+}
+
+// getDataCountForNode (fft_mpi_3d_api.h:78, fft_mpi_3d_api.cpp:274-287): elements of the input slab of every device of this rank
+// (ceil(N0 / P) X-planes each, the last device of the last rank takes the remainder), printed as the reference prints them.
+inline void getDataCountForNode(longInt64 dataCountInNode[], const longInt64 N[], int mpiRank, int mpiSize, int deviceCount,
+                                int deviceCountInNode) {
+    for (int i = 0; i < deviceCountInNode; ++i) {
+        // the reference marks the last device as "last rank, last local index" (:279); the C-ABI names it by its global index
+        const bool last = mpiRank == mpiSize - 1 && i == deviceCountInNode - 1;
+        dataCountInNode[i] = dfft_local_count(N, deviceCount, last ? deviceCount - 1 : 0);
+        printf("data count in device %d of node %d: %lld\n", i, mpiRank, dataCountInNode[i]);  // :285
     }
+}
+
+// fft_mpi_init (fft_mpi_3d_api.cpp:3-39): device-count fix-up, per-device element counts, exchange set-up.
+inline void fft_mpi_init(const longInt64* N, int iniDeviceNumInNode, MPI_Comm comm, int& newDeviceCount,
+                         int& newDeviceCountInNode, longInt64 dataCountInNode[]) {
+    using namespace dfft_api_detail;
+    int mpi_size, mpi_rank;
+    MPI_CHECK(MPI_Comm_size(comm, &mpi_size));
+    MPI_CHECK(MPI_Comm_rank(comm, &mpi_rank));
+    getProperDeviceNum(N, iniDeviceNumInNode, mpi_size, mpi_rank, newDeviceCount, newDeviceCountInNode);      // :21
+    getDataCountForNode(dataCountInNode, N, mpi_rank, mpi_size, newDeviceCount, newDeviceCountInNode);        // :24
     State& s = state();
     std::lock_guard<std::mutex> lk(s.m);
     s.total = newDeviceCount;

@@ -173,6 +173,38 @@ def test_python_mirror_of_init(native_lib):
     assert api.local_size(1024, 768, 512, 8, 7) == (128, 896, 96, 672)
 
 
+def test_reference_named_helpers(native_lib, tmp_path):
+    """getProperDeviceNum / getDataCountForNode / getMaxDataCount under their reference names (fft_mpi_3d_api.h:77-79) against the
+    reference's formulas (fft_mpi_3d_api.cpp:232-316), printed lines included (:270, :285).  No GPU: DFFT_VIRTUAL_DEVICES=1."""
+    import math
+    import os
+    from distributedfft_amd import _lib
+    exe = tmp_path / "ref_helpers"
+    inc = ROOT / "include"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-x", "hip", f"-I{inc}", f"-I{inc / 'dfft_mpi_shim'}",
+                        str(ROOT / "tests" / "helpers" / "ref_helpers_main.cpp"), "-x", "none", "-o", str(exe), f"-L{_lib.LIB_PATH_SYSTEM.parent}",
+                        "-ldfft_mi355x", f"-Wl,-rpath,{_lib.LIB_PATH_SYSTEM.parent}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, DFFT_VIRTUAL_DEVICES="1")
+    for N, ini, size in [((512, 512, 512), 1, 4), ((100, 64, 64), 2, 4), ((1024, 768, 512), 2, 4), ((10, 8, 8), 1, 4), ((7, 8, 8), 4, 2)]:
+        for rank in range(size):
+            want = so.proper_device_num(N, ini, size, rank)
+            r = subprocess.run([str(exe), *map(str, N), str(ini), str(size), str(rank)], capture_output=True, text=True, timeout=60, env=env)
+            if want[1] == 0:  # "could not support this distribution of data, exit!!" (:265-268)
+                assert r.returncode != 0
+                continue
+            assert r.returncode == 0, r.stderr
+            tot, inr = want
+            normal = math.ceil(N[0] / tot) * N[1] * N[2]
+            counts = [N[0] * N[1] * N[2] - normal * (tot - 1) if (rank == size - 1 and i == inr - 1) else normal for i in range(inr)]
+            assert f"allocate {inr} devices to node {rank}" in r.stdout
+            for i, c in enumerate(counts):
+                assert f"data count in device {i} of node {rank}: {c}" in r.stdout
+            res = r.stdout.strip().splitlines()[-1]
+            assert res == "result %d %d %s | max %d %d" % (tot, inr, " ".join(map(str, counts)), so.max_data_count(*N, tot, False),
+                                                           so.max_data_count(*N, tot, True))
+
+
 def test_driver_cli_argument_check(native_lib):
     """fftSpeed3d_c2c.cpp:28-31: exactly four arguments or the format message and a failure exit."""
     from distributedfft_amd import _lib
