@@ -305,3 +305,16 @@ def fft1d_cols(x, direction: int = FORWARD, out=None):
                                          direction, None), "dfft_fft1d_cols")
         torch.cuda.synchronize()
     return out
+
+
+def fft2d_batch(x, direction: int = FORWARD, out=None):
+    """2D FFT of every (n1, n2) plane of a (batch, n1, n2) complex device tensor -- the t0 stage of a 3D plan as a call of its own
+    (dfft_fft2d_batch; templateFFT's FFTDim = 2 application, templateFFT.cpp:5767).  out=x transforms in place."""
+    import torch
+    assert x.is_cuda and x.is_contiguous() and x.dim() == 3
+    out = torch.empty_like(x) if out is None else out
+    with torch.cuda.device(x.device):
+        L.check(L.load().dfft_fft2d_batch(x.data_ptr(), out.data_ptr(), x.shape[1], x.shape[2], x.shape[0], _dtype_code(x), direction,
+                                          None), "dfft_fft2d_batch")
+        torch.cuda.synchronize()
+    return out

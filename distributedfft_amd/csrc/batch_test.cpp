@@ -51,6 +51,13 @@ static int transform(double* buf, long long X, long long Y, long long Z, int dir
 #if BATCH_DIM == 1
     return dfft_fft1d_rows(buf, buf, X, Y * Z, DFFT_F64, dir, s);
 #else
+    // the plan's t0 stage as a call of its own (dfft_fft2d_batch): planes [Y][X], X contiguous -- Infinity-Cache chunking and, for
+    // the plane shapes it is built for, the one-launch stage.  DFFT_BATCH_2D_SEPARATE=1: two whole-buffer 1-D passes (round 5's form)
+    static const bool separate = [] {
+        const char* e = getenv("DFFT_BATCH_2D_SEPARATE");
+        return e && *e == '1';
+    }();
+    if (!separate) return dfft_fft2d_batch(buf, buf, Y, X, Z, DFFT_F64, dir, s);
     int rc;
     if (dir == DFFT_FORWARD) {
         rc = dfft_fft1d_rows(buf, buf, X, Y * Z, DFFT_F64, dir, s);

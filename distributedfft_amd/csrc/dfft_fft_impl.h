@@ -254,20 +254,63 @@ __device__ __forceinline__ void load_twiddles(W* twr, const W* __restrict__ tw, 
     }
 }
 
+// Wave-interleaved labelling of the butterfly ids of a column tile (round 6; see the wave-owned exchange in run_stages).  A tile of CB
+// columns x T butterfly threads spans NW = CB T / 64 wavefronts.  Numbering the threads j = tid / CB puts eight CONSECUTIVE ids into a
+// wavefront; here wavefront w takes the ids congruent to w modulo NW instead: j = w + NW * (lane / CB).  The 8 (16 in fp32) lanes of a
+// column group still cover one full 128-byte line / all 32 LDS banks per access, and which rows of the tile a wavefront touches never
+// mattered to HBM (every row is a line of its own), so nothing changes on the memory side -- but every exchange after the first then
+// stays inside a wavefront.  -DDFFT_WAVE_OWNED=0 builds the tid / CB numbering (A/B).
+#ifndef DFFT_WAVE_OWNED
+#define DFFT_WAVE_OWNED 1
+#endif
+// Where it is used: tiles whose column groups are whole 128-byte lines of 16-byte elements (fp64, fp32 column pairs), one-phase
+// exchanges, and not the staged transposing store of column pairs.  Measured before that rule (profiles/r06/experiments/
+// lib_ab_wave_owned.log): the labelling puts the lanes of a ds_read_b128 group (lanes {0-3, 12-15, 20-27}, ...: four different column
+// groups, MI355X_MICROARCH.md LDS table) on positions 8 apart instead of consecutive ones -- the same half of the 256-byte bank row,
+// 2-way conflicts on every exchange read (cured by lds_pos below) -- and the 8-byte image writes of the pairs' staged store 64 bytes
+// apart instead of 8 (4-way instead of 2-way: 1024-point X pass on pairs 2.82 -> 3.21 ms); 4-column tiles (the paired half-line tiles of
+// the 2048-point X pass) have two column groups per 128 bytes and lose either way (1.87 -> 2.21 ms).
+template <class V, int CB, int T, int PH = 1, bool PAIR_IMAGE = false> constexpr int owned_waves() {
+    constexpr int GT = CB * T;
+    return (DFFT_WAVE_OWNED && sizeof(V) == 16 && (CB * sizeof(V)) % 128 == 0 && !PAIR_IMAGE && PH == 1 && GT % 64 == 0 && GT / 64 > 1 && 64 % CB == 0) ? GT / 64 : 0;
+}
+// Position p of the exchange tile under the labelling: the two 128-byte halves of every 256-byte bank row are swapped in every second
+// group of 8 positions, so that the column groups of a ds_read_b128 lane group -- positions 8 apart -- alternate between the halves.
+// Writes move whole 128-byte slots (an 8-lane ds_write_b128 group stays contiguous).  Identity without the labelling.
+template <int NW> __device__ __forceinline__ constexpr int lds_pos(int p) {
+    if constexpr (NW > 1) return p ^ ((p >> 3) & 1);
+    else return p;
+}
+// butterfly id of thread `tid` of a tile's thread group (groups start at multiples of 64 threads)
+template <int CB, int NW> __device__ __forceinline__ int tile_j(int tid) {
+    if constexpr (NW > 1) return (tid >> 6) + NW * ((tid & 63) / CB);
+    else return tid / CB;
+}
+
+// Row m of a stage's block of the stage-major LDS twiddle table.  Under the wave-interleaved labelling the lanes of a wavefront hold
+// ids 8 (NW) apart, so for a stage with NS > NW their rows m = jq mod NS would lie NW (R - 1) entries apart -- the same banks for every
+// lane group.  The rows are therefore stored in the order the lanes ask for them: m -> (m mod NW) (NS / NW) + m / NW (consecutive lanes,
+// consecutive rows, (R - 1) 16-byte entries = an odd number of bank groups apart).  Identity for NS <= NW and without the labelling.
+template <int NW, int NS> __device__ __forceinline__ constexpr int tw_row(int m) {
+    if constexpr (NW > 1 && NS > NW && NS % NW == 0) return (m % NW) * (NS / NW) + m / NW;
+    else return m;
+}
 // LDS copy of the twiddle table for TW_LDS kernels in stage-major order
-template <class W, class P, int S, int DIR> __device__ __forceinline__ void fill_stage_major(W* dst, const W* __restrict__ tw, int tid, int threads) {
+// (TWS: stride of the source table -- 2 when the stages of an N/2-point plan read the table of the N-point transform, fft_dif2_tiles_kernel)
+template <class W, class P, int S, int DIR, int NW = 0, int TWS = 1>
+__device__ __forceinline__ void fill_stage_major(W* dst, const W* __restrict__ tw, int tid, int threads) {
     if constexpr (S < P::S) {
         using SI = StageInfo<P, S, false>;
         if constexpr (S > 0) {
-            constexpr int R = SI::R, NS = SI::NS, CNT = NS * (R - 1), STRIDE = P::N / (NS * R);
+            constexpr int R = SI::R, NS = SI::NS, CNT = NS * (R - 1), STRIDE = TWS * P::N / (NS * R);
             for (int i = tid; i < CNT; i += threads) {
                 const int m = i / (R - 1), r = i % (R - 1) + 1;
                 W w = tw[r * m * STRIDE];
                 if (DIR < 0) w.y = -w.y;
-                dst[SI::SM_OFF + i] = w;
+                dst[SI::SM_OFF + tw_row<NW, NS>(m) * (R - 1) + (r - 1)] = w;
             }
         }
-        fill_stage_major<W, P, S + 1, DIR>(dst, tw, tid, threads);
+        fill_stage_major<W, P, S + 1, DIR, NW, TWS>(dst, tw, tid, threads);
     }
 }
 // TWMODE: where a stage finds its twiddles.
@@ -280,7 +323,9 @@ enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 // of columns [0, CB/2), then those of [CB/2, CB) -- through one half-size buffer.  HBM accesses keep full 128-byte lines
 // (all CB columns of a row segment are loaded/stored together); only the LDS issue slots double.
 // TWS: stride of the twiddle table behind twr in TW_LDS / TW_GLOBAL mode (2: the table of a transform twice as long)
-template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW, int PH = 1, int TWS = 1>
+// NW: waves per tile under the wave-interleaved labelling of the butterfly ids (wave_owned_j below), 0 = threads numbered tid / CB
+// LOCALX: thread-local exchanges are renamings (below); false keeps them in LDS for kernels that have no register to spare
+template <class V, class P, int S, int DIR, int CB, bool PAD, bool WAVE_LOCAL, int TWMODE, bool TWPOW, int PH = 1, int TWS = 1, int NW = 0, bool LOCALX = true>
 __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W* twr, V* lds, int j, int c) {
     using SI = StageInfo<P, S, TWPOW>;
     using W = typename VecTraits<V>::W;
@@ -293,7 +338,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
         if constexpr (S > 0) {
 #if DFFT_TW_STAGE_MAJOR
             if constexpr (TWMODE == TW_LDS && TWS == 1) {
-                const W* ts = twr + SI::SM_OFF + ((j + q * T) % NS) * (R - 1);
+                const W* ts = twr + SI::SM_OFF + tw_row<NW, NS>((j + q * T) % NS) * (R - 1);
 #pragma unroll
                 for (int r = 1; r < R; ++r) u[r] = cmul(u[r], ts[r - 1]);
             } else
@@ -334,7 +379,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
     if constexpr (S + 1 < P::S) {
 #ifdef DFFT_DBG_NOEXCH
         // measurement builds only (-DDFFT_DBG_NOEXCH): skip the LDS exchange to see the HBM + VALU time alone (wrong results)
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS, NW, LOCALX>(v, twr, lds, j, c);
         return;
 #endif
         // Thread-local exchange (round 6).  The scatter after stage S sends the result (jq, r) to position
@@ -350,7 +395,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
 #ifndef DFFT_LOCAL_EXCHANGE
 #define DFFT_LOCAL_EXCHANGE 1
 #endif
-        if constexpr (DFFT_LOCAL_EXCHANGE && NS % T == 0) {
+        if constexpr (DFFT_LOCAL_EXCHANGE && LOCALX && NS % T == 0) {
             V t[E];
 #pragma unroll
             for (int q = 0; q < B; ++q)
@@ -359,7 +404,17 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] = t[k];
         } else if constexpr (PH == 1) {
-            if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WAVE_LOCAL>();  // WAR: previous readers are done
+            // Wave-owned exchange (round 6).  Under the wave-interleaved labelling (wave of butterfly id j = j mod NW, wave_owned_j) a
+            // thread READS positions j + T k of the tile in every exchange -- positions congruent to its wave's index modulo NW (NW
+            // divides T) -- and WRITES positions congruent to jq mod NS modulo NW whenever NW divides NS: its own wave's again.  From
+            // the first exchange with NW | NS on, every wave therefore reads and writes only its own residue class of the tile: no other
+            // wave touches it, DS operations of one wave execute in issue order, and the two workgroup barriers of the exchange shrink to
+            // compiler fences.  With radix-8 first stages and 8 waves per tile that is every exchange but the first: 512 = 8 8 8 keeps 2
+            // of 4 barriers per tile, 1024 = 8 8 [8 2] 2 of 4, 2048 = 8 8 8 4 2 of 6 (plus the two of a staged store).  The labelling
+            // changes which lane computes a butterfly, not what is computed: bit-identical results.
+            constexpr bool OWNED = NW > 1 && S > 0 && NS % NW == 0 && T % NW == 0;
+            constexpr bool WL = WAVE_LOCAL || OWNED;
+            if constexpr (S > 0 || !WAVE_LOCAL) group_sync<WL>();  // WAR: previous readers are done
             // Padded rows (one element per 8): where the step between a thread's accesses is a multiple of 8 elements the
             // padded index is affine in the access number -- written out that way so that the accesses become ONE address
             // register plus immediate offsets (left to itself the compiler keeps an address register per access alive across
@@ -375,19 +430,42 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
                     constexpr int step = (NS % 8 == 0 ? NS + NS / 8 : 1) * CB;
 #pragma unroll
                     for (int r = 0; r < R; ++r) lds[pb + r * step] = v[q + r * B];
+                } else if constexpr (NW > 1) {
+                    // positions lds_pos(base + r NS) written as ONE or TWO base registers plus compile-time offsets (left as the XOR
+                    // the compiler keeps an address register per access: the 16-point column kernels spill)
+                    if constexpr (NS % 16 == 0) {  // bit 3 of the position comes from base alone
+                        const int b = lds_pos<NW>(base) * CB + c;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) lds[b + r * NS * CB] = v[q + r * B];
+                    } else if constexpr ((NS == 8 && R % 2 == 0) || (NS == 4 && R == 4)) {  // ... from r alone: r odd (NS = 8), r >= 2 (NS = 4)
+                        const int b0 = base * CB + c, b1 = (base ^ 1) * CB + c;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) lds[((NS == 8 ? r & 1 : (r >> 1) & 1) ? b1 : b0) + r * NS * CB] = v[q + r * B];
+                    } else if constexpr (NS == 1 && (R == 8 || R == 4)) {  // ... from base, bit 0 from r: r ^ bit = r + bit (r even), r - bit (r odd)
+                        const int bit = (base >> 3) & 1, b0 = (base + bit) * CB + c, b1 = (base - bit) * CB + c;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) lds[((r & 1) ? b1 : b0) + r * CB] = v[q + r * B];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) lds[lds_pos<NW>(base + r * NS) * CB + c] = v[q + r * B];
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; ++r) lds[lds_index<CB, PAD>(base + r * NS, c)] = v[q + r * B];
                 }
             }
-            group_sync<WAVE_LOCAL>();
+            group_sync<WL>();
             if constexpr (RAFF) {
                 const int pj = lds_index<CB, PAD>(j, c);
 #pragma unroll
                 for (int k = 0; k < E; ++k) v[k] = lds[pj + k * ((T + T / 8) * CB)];
+            } else if constexpr (NW > 1 && T % 16 == 0) {
+                const int pj = lds_pos<NW>(j) * CB + c;  // (T k does not reach bit 3)
+#pragma unroll
+                for (int k = 0; k < E; ++k) v[k] = lds[pj + k * T * CB];
             } else {
 #pragma unroll
-                for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(j + T * k, c)];
+                for (int k = 0; k < E; ++k) v[k] = lds[lds_index<CB, PAD>(lds_pos<NW>(j + T * k), c)];
             }
         } else {
             static_assert(PH == 1 || (!PAD && !WAVE_LOCAL && CB % PH == 0), "two-phase exchange: block-wide column tiles");
@@ -412,7 +490,7 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
                 }
             }
         }
-        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS>(v, twr, lds, j, c);
+        run_stages<V, P, S + 1, DIR, CB, PAD, WAVE_LOCAL, TWMODE, TWPOW, PH, TWS, NW, LOCALX>(v, twr, lds, j, c);
     }
 }
 
@@ -428,6 +506,15 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     // columns each (run_stages): full 128-byte lines on the HBM side without a 256 KiB exchange buffer
     static constexpr int PH = (P::S > 1 && CB > 1 && (size_t)P::N * CB * sizeof(V) > 128 * 1024) ? 2 : 1;
     static_assert(CB % PH == 0 && P::E % PH == 0, "two-phase tiles need an even column count and an even E");
+    // wave-interleaved butterfly ids (0: tid / CB).  Not for the plain column kernels with per-point rotated offsets (the rotated side of a
+    // P > 1 plan's X pass without a staged store): they sit at the register limit (see LOCALX) and the second base register of the
+    // swizzled exchange tips the 768-point ones over
+    static constexpr bool ROT2_PLAIN = Tune::ROT && (Tune::ROT_IN == 2 || Tune::ROT_OUT == 2) && !OSTAGE;
+    static constexpr int  NW = ROT2_PLAIN ? 0 : owned_waves<V, CB, P::T, PH, Tune::OSTAGE && VecTraits<V>::LANES == 2>();
+    // 16 points of 16 bytes per thread with per-point rotated offsets and no staged store (the rotated side of a P > 1 plan's backward
+    // X pass at 1024 points): these kernels sit AT 256 registers, and with the last two stages back to back (thread-local exchange) the
+    // compiler goes 28-44 bytes over -- they keep that exchange in LDS (kernel_resources: 0 B either way in round 5's form)
+    static constexpr bool LOCALX = !(ROT2_PLAIN && P::E * (int)sizeof(V) / 4 >= 64);
     static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB / PH : 0;
     // staged image: one scalar column per row of N + OPAD twiddle-typed elements (OPAD = 2 keeps cpair rows 16-B aligned)
     static constexpr int LANES = VecTraits<V>::LANES;
@@ -533,7 +620,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
     const int g = threadIdx.x / GT;
     const int tid = threadIdx.x - g * GT;
     const int c = tid % CB;
-    const int j = tid / CB;
+    const int j = tile_j<CB, KG::NW>(tid);
 
     constexpr int TWN = KG::TWMODE == TW_REG ? KG::TWN : 0;
     W twreg[TWN > 0 ? TWN : 1];
@@ -542,7 +629,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
         twr = tw;
     } else if constexpr (KG::TWMODE == TW_LDS) {
 #if DFFT_TW_STAGE_MAJOR
-        fill_stage_major<W, P, 0, DIR>(ldstw, tw, (int)threadIdx.x, KG::THREADS);
+        fill_stage_major<W, P, 0, DIR, KG::NW>(ldstw, tw, (int)threadIdx.x, KG::THREADS);
 #else
         for (int i = threadIdx.x; i < N; i += KG::THREADS) {
             W w = tw[i];
@@ -724,7 +811,7 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             load_tile(t0, v);
         }
 
-        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW, KG::PH>(v, twr, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW, KG::PH, 1, KG::NW, KG::LOCALX>(v, twr, lds, j, c);
 
         // normalisation folded into this pass: every result is multiplied on its way out (x * 1.0 is exact, so the default
         // changes nothing; a branch around a separate scaling loop cost 15 VGPRs and made the 16-point kernels spill)
@@ -845,9 +932,10 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     W* ldstw = reinterpret_cast<W*>(dfft_smem);
     V* lds = reinterpret_cast<V*>(dfft_smem + TW_BYTES);
-    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    constexpr int NWV = owned_waves<V, CB, T, 1, LANES == 2>();  // (half-line tiles: 0 -- see owned_waves)
+    const int tid = threadIdx.x, c = tid % CB, j = tile_j<CB, NWV>(tid);
 #if DFFT_TW_STAGE_MAJOR
-    fill_stage_major<W, P, 0, DIR>(ldstw, tw, tid, GT);
+    fill_stage_major<W, P, 0, DIR, NWV>(ldstw, tw, tid, GT);
 #else
     for (int i = tid; i < N; i += GT) {
         W w = tw[i];
@@ -901,7 +989,7 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     };
     // One half of a tile pair: the 4-column transform through the LDS tile, the staged image, the transposing store.
     auto process_half = [&](V* v, GV* oh) {
-        run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1>(v, ldstw, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1, 1, NWV>(v, ldstw, lds, j, c);
         W* img = reinterpret_cast<W*>(lds);
         __syncthreads();
 #pragma unroll
@@ -1000,7 +1088,7 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             V* v = h == 0 ? v0 : v1;
-            run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1>(v, ldstw, lds, j, c);
+            run_stages<V, P, 0, DIR, CB, false, false, TW_LDS, false, 1, 1, NWV>(v, ldstw, lds, j, c);
             W* img = reinterpret_cast<W*>(lds);
             __syncthreads();
 #pragma unroll
@@ -1058,12 +1146,35 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     W* ldstw = reinterpret_cast<W*>(dfft_smem);  // N entries; the NH-point stages use every second one
     V* lds = reinterpret_cast<V*>(dfft_smem + Dif2Geom<V, PH, CB>::TW_BYTES);
-    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    constexpr int NWV = owned_waves<V, CB, T>();
+    const int tid = threadIdx.x, c = tid % CB, j = tile_j<CB, NWV>(tid);
+#if DFFT_TW_STAGE_MAJOR
+    // (round 6) the same N entries of LDS, laid out for the lanes that read them: [0, NH) the stage-major table of the NH-point stages
+    // (every second entry of the N-point table, rows in lane order: tw_row), [NH, N) the first-stage factors W_N^n, n = j + T k, as
+    // [k][ids in lane order] -- under the wave-interleaved labelling the lanes of a wavefront hold ids NW apart, and read from the
+    // natural-order table they would all hit the same banks
+    constexpr int TWS_RUN = 1;
+    W*            ldsf = ldstw + NH;
+    fill_stage_major<W, PH, 0, DIR, NWV, 2>(ldstw, tw, tid, GT);
+    auto fperm = [](int jj) -> int {
+        if constexpr (NWV > 1) return (jj % NWV) * (T / NWV) + jj / NWV;
+        else return jj;
+    };
+    for (int i = tid; i < NH; i += GT) {
+        W w = tw[i];
+        if (DIR < 0) w.y = -w.y;
+        ldsf[(i / T) * T + fperm(i % T)] = w;
+    }
+    const W* fst = ldsf + fperm(j);  // factor of point k: fst[T k]
+#else
+    constexpr int TWS_RUN = 2;
     for (int i = tid; i < N; i += GT) {
         W w = tw[i];
         if (DIR < 0) w.y = -w.y;
         ldstw[i] = w;
     }
+    const W* fst = ldstw + j;
+#endif
     __syncthreads();
     // Multi-block sides: the launcher guarantees imap.blk % T == 0 and omap.blk % (2 T) == 0, so the block a point falls into
     // depends on k alone -- a wave-uniform 32-bit term per k (computed once) plus ONE per-thread term.  Plain sides: k * step.
@@ -1127,10 +1238,10 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
         const V sum = cadd(x0, x1);
         const V dif = csub(x0, x1);
         x0 = sum;
-        x1 = cmul(dif, ldstw[j + T * k]);  // W_N^{j + T k}
+        x1 = cmul(dif, fst[T * k]);  // W_N^{j + T k}
     };
     auto process_half = [&](V* v, unsigned t, int h) {
-        run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, 2>(v, ldstw, lds, j, c);
+        run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, TWS_RUN, NWV>(v, ldstw, lds, j, c);
         GV* op = out_ptr(t);
 #pragma unroll
         for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
@@ -1208,12 +1319,12 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
             const V sum = cadd(v0[k], v1[k]);
             const V dif = csub(v0[k], v1[k]);
             v0[k] = sum;
-            v1[k] = cmul(dif, ldstw[j + T * k]);  // W_N^{j + T k}
+            v1[k] = cmul(dif, fst[T * k]);  // W_N^{j + T k}
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             V* v = h == 0 ? v0 : v1;
-            run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, 2>(v, ldstw, lds, j, c);
+            run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, TWS_RUN, NWV>(v, ldstw, lds, j, c);
 #pragma unroll
             for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
         }
@@ -1250,7 +1361,7 @@ fft_tload_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     W* ldstw = reinterpret_cast<W*>(dfft_smem);
     V* lds = reinterpret_cast<V*>(dfft_smem + KG::TW_BYTES);
-    const int tid = threadIdx.x, c = tid % CB, j = tid / CB;
+    const int tid = threadIdx.x, c = tid % CB, j = tile_j<CB, KG::NW>(tid);
     constexpr int TWN = KG::TWMODE == TW_REG ? KG::TWN : 0;
     W        twreg[TWN > 0 ? TWN : 1];
     const W* twr = twreg;
@@ -1258,7 +1369,7 @@ fft_tload_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>
         twr = tw;
     } else if constexpr (KG::TWMODE == TW_LDS) {
 #if DFFT_TW_STAGE_MAJOR
-        fill_stage_major<W, P, 0, DIR>(ldstw, tw, tid, GT);
+        fill_stage_major<W, P, 0, DIR, KG::NW>(ldstw, tw, tid, GT);
 #else
         for (int i = tid; i < N; i += GT) {
             W w = tw[i];
@@ -1319,7 +1430,7 @@ fft_tload_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>
             }
         }
         __syncthreads();  // the image is read before the first exchange overwrites it
-        run_stages<V, P, 0, DIR, CB, false, false, KG::TWMODE, TWPOW, 1>(v, twr, lds, j, c);
+        run_stages<V, P, 0, DIR, CB, false, false, KG::TWMODE, TWPOW, 1, 1, KG::NW>(v, twr, lds, j, c);
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         const int      ob0 = (int)(b * CB);
         GV*            op = out + (long long)a * otile.a_stride + (long long)ob0 * otile.b_stride;

@@ -22,6 +22,8 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <string>
+#include <tuple>
 #include <thread>
 
 #include "dfft_internal.h"
@@ -1888,8 +1890,162 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
     return fft_rows(in, out, (int)n, batch, dtype, direction, (hipStream_t)stream);
 }
 
+// ---- batched 2D transform: the plan's t0 stage as an entry point of its own ------------------------------------
+// State of the one-launch stage for one (device, stream, plane shape, structure): the kernel's control block, its pinned error word and
+// the host's running ticket / execute counters (dfft_zy.hip) -- what a plan keeps in dfft_plan_s, cached here because the call is
+// plan-less.  Freed by dfft_trim().
+namespace {
+struct Zy2dCtx {
+    ZyCtl*    ctl = nullptr;
+    unsigned* err = nullptr;
+    unsigned  ticket = 0, execs = 0;
+    bool      off = false;  // a launch gave up: this context stays on two launches per chunk
+};
+struct Zy2dKey {
+    int         dev;
+    hipStream_t stream;
+    int         n1, n2, sign;
+    bool        operator<(const Zy2dKey& o) const { return std::tie(dev, stream, n1, n2, sign) < std::tie(o.dev, o.stream, o.n1, o.n2, o.sign); }
+};
+std::mutex                 g_zy2d_mutex;
+std::map<Zy2dKey, Zy2dCtx> g_zy2d;
+
+void zy2d_trim() {
+    std::lock_guard<std::mutex> lk(g_zy2d_mutex);
+    int                         cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_zy2d) {
+        (void)hipSetDevice(kv.first.dev);
+        (void)hipDeviceSynchronize();
+        if (kv.second.ctl) (void)hipFree(kv.second.ctl);
+        if (kv.second.err) (void)hipHostFree(kv.second.err);
+    }
+    g_zy2d.clear();
+    (void)hipSetDevice(cur);
+}
+}  // namespace
+
+// `batch` planes of [n1][n2] (n2 contiguous), each transformed along both axes; in place (out == in) or out of place (`in` is left
+// untouched).  What a 3D plan runs as t0 (reference fftZY, fft_mpi_3d_api.cpp:466-522; templateFFT's FFTDim = 2 application,
+// templateFFT.cpp:5767): planes are taken in groups that fit the 256 MiB Infinity Cache, so the column pass reads what the row pass
+// wrote from the cache, and plane shapes the one-launch stage is built for (dfft_zy.hip: fp64, n1 in {256, 512, 768 (n2 = 512)}, n2 in
+// {256, 512}) run as ONE persistent launch.  Forward: rows n2 then columns n1; backward: the same order with conjugated twiddles
+// (the two 1-D transforms of a plane commute).  Un-normalised.
+int dfft_fft2d_batch(void* in, void* out, long long n1, long long n2, long long batch, int dtype, int direction, void* stream) {
+    if (!in || !out || n1 < 1 || n2 < 1 || batch < 0 || (dtype != DFFT_F64 && dtype != DFFT_F32) || (direction != DFFT_FORWARD && direction != DFFT_BACKWARD))
+        return fail(DFFT_EINVAL, "dfft_fft2d_batch: bad arguments");
+    if (!dfft_length_supported(n1) || !dfft_length_supported(n2)) return fail(DFFT_EUNSUPPORTED, "dfft_fft2d_batch: unsupported length");
+    if (dfft_device_count() < 1) return fail(DFFT_ENOGPU, "dfft_fft2d_batch: no HIP device visible (no CPU fallback)");
+    if (batch == 0) return DFFT_OK;
+    hipStream_t     s = (hipStream_t)stream;
+    const long long plane = n1 * n2, plane_b = plane * (long long)elem_bytes(dtype);
+    if (n1 > 4096 || n2 > 4096 || plane >= (1ll << 31)) {  // four-step axes: whole-buffer passes on the 1-D entry points
+        int rc = dfft_fft1d_rows(in, out, n2, n1 * batch, dtype, direction, stream);
+        if (rc == DFFT_OK) rc = dfft_fft1d_cols(out, out, n1, n2, batch, dtype, direction, stream);
+        return rc;
+    }
+    static const bool one_launch_off = [] {
+        const char* e = getenv("DFFT_T0_ONE_LAUNCH");
+        return e && *e == '0';
+    }();
+    // ---- one persistent launch
+    if (!one_launch_off && zy_supported(dtype, (int)n1, (int)n2) && batch <= ZY_MAX_PLANES) {
+        int dev = 0;
+        DFFT_HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(g_zy2d_mutex);
+        Zy2dCtx&                    c = g_zy2d[Zy2dKey{dev, s, (int)n1, (int)n2, direction}];
+        if (!c.off && !c.ctl) {
+            // (zeroed on the caller's stream and waited for, like a plan's: dfft_plan_create)
+            if (hipMalloc((void**)&c.ctl, sizeof(ZyCtl)) != hipSuccess || hipMemsetAsync(c.ctl, 0, sizeof(ZyCtl), s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess || hipHostMalloc((void**)&c.err, 128, hipHostMallocMapped) != hipSuccess) {
+                (void)hipGetLastError();
+                if (c.ctl) (void)hipFree(c.ctl);
+                c.ctl = nullptr;
+                c.off = true;
+            } else {
+                *c.err = 0u;
+            }
+        }
+        if (!c.off && *(volatile unsigned*)c.err != 0u) {
+            c.off = true;  // sticky on the device side too: every later launch on this block would return at once
+            return fail(DFFT_EHIP, "dfft_fft2d_batch: an earlier one-launch YZ stage on this stream gave up; the results of that call and of every call queued "
+                                   "behind it are invalid, later calls use two launches per chunk");
+        }
+        if (!c.off) {
+            const void *twz = nullptr, *twy = nullptr;
+            DFFT_TRY(get_twiddles((int)n2, dtype, &twz));
+            DFFT_TRY(get_twiddles((int)n1, dtype, &twy));
+            ZyLaunch L;
+            std::memset(&L, 0, sizeof(L));
+            L.dtype = dtype;
+            L.n1 = (int)n1;
+            L.n2 = (int)n2;
+            L.dir = +1;  // rows first in both directions (the inverse: SIGN = -1, dfft_zy.hip)
+            L.sign = direction;
+            L.src = in;
+            L.w = out;
+            L.dst = nullptr;
+            L.src_plane = L.w_plane = L.dst_plane = plane;
+            DFFT_ZY_SET_PITCH(L, n2);
+            L.plane0 = 0;
+            L.nplanes = batch;
+            const long long fit = std::max(1ll, (230ll << 20) / plane_b), nch = (batch + fit - 1) / fit;
+            L.chunk = batch * plane_b <= (256ll << 20) ? batch : (batch + nch - 1) / nch;  // zy_phase_planes
+            L.ctl = c.ctl;
+            L.twz = twz;
+            L.twy = twy;
+            L.lazy = 1;
+            static const unsigned polls = [] {
+                const char* sp = getenv("DFFT_ZY_SPIN_POLLS");
+                return sp && atoll(sp) > 0 ? (unsigned)std::min(atoll(sp), 0xffffffffll) : (4u << 20);
+            }();
+            L.spin_polls = polls;
+            if (hipHostGetDevicePointer((void**)&L.err_host, c.err, 0) != hipSuccess) return fail(DFFT_EHIP, "dfft_fft2d_batch: no device pointer for the error word");
+            unsigned producers = 0;
+            (void)zy_units_per_plane(L.n1, L.n2, L.dir, 0, &producers);
+            L.ticket_base = c.ticket;
+            L.done_base = c.execs * producers;
+            ++c.execs;
+            c.ticket += zy_tickets(L.n1, L.n2, L.dir, 0, L.nplanes, L.chunk);
+            return check_launch(launch_zy(L, s), "dfft_fft2d_batch (one-launch YZ stage)");
+        }
+    }
+    // ---- two launches per Infinity-Cache chunk (dfft_plan_create's rule for single-GPU plans)
+    long long cp = batch;
+    if (batch * plane_b > (256ll << 20)) {
+        long long fit = std::max(1ll, (256ll << 20) / plane_b);
+        if (plane_b >= (8ll << 20) && fit > 1) --fit;
+        const long long nchunks = std::max(1ll, (batch + fit - 1) / fit);
+        cp = (batch + nchunks - 1) / nchunks;
+    }
+    const void* twy = nullptr;
+    DFFT_TRY(get_twiddles((int)n1, dtype, &twy));
+    const bool chunked = cp < batch;
+    for (long long x0 = 0; x0 < batch; x0 += cp) {
+        const long long nx = std::min(cp, batch - x0);
+        DFFT_TRY(fft_rows(in, out, (int)n2, nx * n1, dtype, direction, s, x0 * n1, (chunked && in != out) ? FFT_HINT_STREAM_IN : 0));
+        FftLaunch L;
+        std::memset(&L, 0, sizeof(L));
+        L.dtype = dtype;
+        L.n = (int)n1;
+        L.dir = direction;
+        L.cols = 1;
+        L.in = out;
+        L.out = out;
+        L.tw = twy;
+        L.imap = L.omap = plain_axis(n1, n2, 1);
+        L.itile = L.otile = TileMap{plane, 1};
+        L.na = nx;
+        L.a_first = x0;
+        L.ncols = (int)n2;
+        DFFT_TRY(check_launch(launch_fft(L, s), "dfft_fft2d_batch (columns)"));
+    }
+    return DFFT_OK;
+}
+
 int dfft_trim(void) {
     long_scratch_trim();
+    zy2d_trim();
     return DFFT_OK;
 }
 

@@ -107,7 +107,10 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
 
     const int tid = threadIdx.x;
     const int gz = tid / TZ, jz = tid % TZ;  // row unit: row gz of the unit, butterfly id jz
-    const int cy = tid % CB, jy = tid / CB;  // column unit: column cy of the tile, butterfly id jy
+    // wave-interleaved butterfly ids of the column units (dfft_fft_impl.h, tile_j); not in the eager 768-point kernels -- the tests' bit-identity
+    // reference, not a shipped path -- which have no register left for the swizzled exchange's second base
+    constexpr int NWY = (!LAZY && PY::N == 768) ? 0 : owned_waves<V, CB, TY>();
+    const int cy = tid % CB, jy = tile_j<CB, NWY>(tid);  // column unit: column cy of the tile, butterfly id jy
     V*        lds_row = lds + gz * ROW_LDS;
 
     constexpr int TWNZ = TWPZ ? TwTotal<PZ, true>::value : 0, TWNY = TWPY ? TwTotal<PY, true>::value : 0;
@@ -120,7 +123,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     }
     if constexpr (TWPY) load_twiddles<V, PY, 0, SIGN, true>(twyr, twy, jy);
     else {
-        fill_stage_major<V, PY, 0, SIGN>(ldstwy, twy, tid, THREADS);
+        fill_stage_major<V, PY, 0, SIGN, NWY>(ldstwy, twy, tid, THREADS);
         twyp = ldstwy;
     }
     if constexpr (!TWPZ || !TWPY) __syncthreads();
@@ -307,7 +310,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
             run_stages<V, PZ, 0, SIGN, 1, true, true, TWMZ, TWPZ>(v, twzp, lds_row, jz, 0);
         } else {
             __syncthreads();  // the LDS rows of an earlier row unit are no longer read
-            run_stages<V, PY, 0, SIGN, CB, false, false, TWMY, TWPY>(v, twyp, lds, jy, cy);
+            run_stages<V, PY, 0, SIGN, CB, false, false, TWMY, TWPY, 1, 1, NWY>(v, twyp, lds, jy, cy);
         }
     };
     auto store_unit = [&](const Item& it, const V* v) {

@@ -207,7 +207,19 @@ int dfft_fft1d_rows(void* in, void* out, long long n, long long batch, int dtype
 int dfft_fft1d_cols(void* in, void* out, long long n, long long width, long long batch, int dtype, int direction,
                     void* stream);
 
-/* Frees the scratch buffers the 1-D entry points cache per (device, stream) for lengths above 4096 (four-step transforms).
+/* ---- batched 2D transform (templateFFT's FFTDim = 2 application: initializeFFT, templateFFT.cpp:5767, launched by fftZY,
+ * fft_mpi_3d_api.cpp:466-522; component benchmark templateFFT/batchTest/Test_2D.cpp:29-198) ---------------------------------
+ * `batch` planes of [n1][n2] complex elements (n2 contiguous), each transformed along both axes, in place (out == in) or out
+ * of place (`in` is left untouched).  This is the t0 stage of a 3D plan as an entry point of its own: planes are processed in
+ * groups that fit the 256 MiB Infinity Cache (the column pass reads what the row pass wrote from the cache), and the plane
+ * shapes the one-launch stage is built for (fp64; n1 = 256 / 512 with n2 = 256 / 512, n1 = 768 with n2 = 512) run as ONE
+ * persistent launch per call.  Un-normalised in both directions.  The one-launch form keeps a small control block per (device,
+ * stream, plane shape, direction), freed by dfft_trim(); a launch that gives up (see dfft_zy.hip) is reported by the next call
+ * on that stream, which -- like every later one -- runs on two launches per chunk. */
+int dfft_fft2d_batch(void* in, void* out, long long n1, long long n2, long long batch, int dtype, int direction, void* stream);
+
+/* Frees the scratch buffers the 1-D entry points cache per (device, stream) for lengths above 4096 (four-step transforms) and the
+ * control blocks of dfft_fft2d_batch.
  * Buffers in use by a call in progress are left alone.  No counterpart in the reference. */
 int dfft_trim(void);
 

@@ -54,6 +54,54 @@ def test_fft1d_rows_vs_oracle(gpu, n, prec):
     assert _rel_err(y.cpu().numpy(), ref_f) < TOL[prec]
 
 
+# plane shapes of the reference's published 2D table (templateFFT/csv/batch_result2D.csv: powers of two 128 ... 2048, 120 x 120, 240 x 100,
+# 245 x 245, 360 x 360, 243 x 243, 729 x 243, 625 x 125, 343 x 343), the shapes of the one-launch stage (256 / 512 / 768-point axes) with plane
+# counts that make one, two and several Infinity-Cache phases, odd / ragged widths, a four-step axis
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("n1,n2,batch", [(512, 512, 3), (256, 256, 70), (512, 256, 5), (256, 512, 131), (768, 512, 40), (512, 512, 70),
+                                         (2048, 2048, 2), (1024, 512, 3), (128, 2048, 4), (2048, 128, 4), (120, 120, 9), (100, 240, 5),
+                                         (245, 245, 3), (360, 360, 2), (243, 243, 4), (243, 729, 2), (125, 625, 3), (343, 343, 2),
+                                         (64, 21, 7), (7, 8, 5), (2, 16, 3), (16, 2, 3), (8192, 8, 2)])
+def test_fft2d_batch_vs_numpy(gpu, n1, n2, batch, prec):
+    """dfft_fft2d_batch (the plan's t0 as an entry point: Infinity-Cache chunks, one-launch stage where built) against np.fft.fft2,
+    forward and backward, out of place (input untouched) and in place."""
+    import torch
+    from distributedfft_amd import api
+    rng = np.random.default_rng(n1 * 4099 + n2)
+    x = (rng.uniform(-1, 1, (batch, n1, n2)) + 1j * rng.uniform(-1, 1, (batch, n1, n2)))
+    xt = torch.from_numpy(x).to(gpu).to(_torch_dtype(prec))
+    keep = xt.clone()
+    ref = np.fft.fft2(x, axes=(1, 2))
+    got = api.fft2d_batch(xt, api.FORWARD).cpu().numpy()
+    assert _rel_err(got, ref) < TOL[prec], f"2D {n1}x{n2}x{batch}"
+    assert torch.equal(xt, keep)  # out of place: the input is left alone
+    back = api.fft2d_batch(xt, api.BACKWARD).cpu().numpy()
+    assert _rel_err(back, np.fft.ifft2(x, axes=(1, 2)) * (n1 * n2)) < TOL[prec]
+    assert torch.equal(xt, keep)
+    y = xt.clone()
+    api.fft2d_batch(y, api.FORWARD, out=y)
+    assert _rel_err(y.cpu().numpy(), ref) < TOL[prec]
+    api.fft2d_batch(y, api.BACKWARD, out=y)  # round trip in place
+    assert _rel_err(y.cpu().numpy() / (n1 * n2), x) < TOL[prec] * 10
+
+
+def test_fft2d_batch_is_the_plans_t0(gpu):
+    """Same planes through dfft_fft2d_batch and through two whole-buffer 1-D passes: the one-launch form within 1e-14 of the 1-D
+    entry points (lazy publish: last bit or two), calls repeat bit for bit, dfft_trim() drops the cached control blocks."""
+    import torch
+    from distributedfft_amd import _lib, api
+    g = torch.Generator(device=gpu)
+    g.manual_seed(7)
+    x = (torch.rand(96, 512, 512, generator=g, device=gpu, dtype=torch.float64) - 0.5).to(torch.complex128)
+    a = api.fft2d_batch(x)
+    b = api.fft2d_batch(x)
+    assert torch.equal(a, b)
+    c = api.fft1d_cols(api.fft1d_rows(x.reshape(-1, 512)).reshape(96, 512, 512))
+    assert float((a - c).abs().max() / c.abs().max()) < 1e-14
+    assert _lib.load().dfft_trim() == 0
+    assert torch.equal(api.fft2d_batch(x), a)
+
+
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 @pytest.mark.parametrize("n", LENGTHS)
 # full tiles / ragged last tile with an odd column count (GENERAL variant; fp32 cannot pair columns) / ragged, even
