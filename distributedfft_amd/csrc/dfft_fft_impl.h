@@ -126,6 +126,17 @@ template <class Base> struct Plain : Base {
     static constexpr bool PLAIN = true;
 };
 
+// A side of the launch whose COLUMNS are far apart in memory and whose FFT index is the contiguous one, accessed directly (no staged
+// image): the inverse X pass of fp64 plans reads [..][z][kx] that way, ragged / un-stageable forward X passes store it.  There the
+// lanes of 8 consecutive butterfly ids of one column form the 128-byte pieces, so the wave-interleaved labelling (ids 8 apart in a
+// wavefront) would turn every piece into eight 16-byte accesses (measured: inverse X pass of 1024 x 768 x 512 fp64 2.46 -> 3.45 ms);
+// these launches keep the tid / CB numbering.
+template <class Base> struct TransposedSide : Base {
+    static constexpr bool NO_OWNED = true;
+};
+template <class T, class = void> struct tune_no_owned : std::false_type {};
+template <class T> struct tune_no_owned<T, std::void_t<decltype(T::NO_OWNED)>> : std::bool_constant<T::NO_OWNED> {};
+
 // Cache-policy variants for the Infinity-Cache-blocked Z+Y stage (execute_forward/backward in dfft_plan.cpp).
 struct TuneStreamIn : TuneDefault {
     static constexpr bool NTL = true;
@@ -510,11 +521,13 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     // P > 1 plan's X pass without a staged store): they sit at the register limit (see LOCALX) and the second base register of the
     // swizzled exchange tips the 768-point ones over
     static constexpr bool ROT2_PLAIN = Tune::ROT && (Tune::ROT_IN == 2 || Tune::ROT_OUT == 2) && !OSTAGE;
-    static constexpr int  NW = ROT2_PLAIN ? 0 : owned_waves<V, CB, P::T, PH, Tune::OSTAGE && VecTraits<V>::LANES == 2>();
+    static constexpr int  NW = (ROT2_PLAIN || tune_no_owned<Tune>::value) ? 0 : owned_waves<V, CB, P::T, PH, Tune::OSTAGE && VecTraits<V>::LANES == 2>();
     // 16 points of 16 bytes per thread with per-point rotated offsets and no staged store (the rotated side of a P > 1 plan's backward
     // X pass at 1024 points): these kernels sit AT 256 registers, and with the last two stages back to back (thread-local exchange) the
     // compiler goes 28-44 bytes over -- they keep that exchange in LDS (kernel_resources: 0 B either way in round 5's form)
-    static constexpr bool LOCALX = !(ROT2_PLAIN && P::E * (int)sizeof(V) / 4 >= 64);
+    // (likewise the one-wavefront rows of 2048 fp64 points, 32 points = 128 registers of data per thread: 400 -> 440 registers and
+    // 0.42 -> 0.455 ms per GiB with the exchange in registers, profiles/r06/experiments/long_axis_kernels_ab.txt)
+    static constexpr bool LOCALX = !(ROT2_PLAIN && P::E * (int)sizeof(V) / 4 >= 64) && !(CB == 1 && P::E * (int)sizeof(V) / 4 >= 128);
     static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB / PH : 0;
     // staged image: one scalar column per row of N + OPAD twiddle-typed elements (OPAD = 2 keeps cpair rows 16-B aligned)
     static constexpr int LANES = VecTraits<V>::LANES;
@@ -1885,6 +1898,21 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneColsStreamIn>>(L, stream);
                 return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneCols>>(L, stream);
             }
+        }
+        // a directly accessed transposed side (see TransposedSide): the twin without the wave-interleaved labelling, where the two differ
+        const bool tr_side = !(L.imap.cstride == 1 && L.itile.b_stride == 1) || (!(L.omap.cstride == 1 && L.otile.b_stride == 1) && !(can_stage && staged));
+        using TSCols = std::conditional_t<(KernelGeom<V, P, CBC, GC, TuneCols>::NW > 0), TransposedSide<TuneCols>, TuneCols>;
+        using TSColsIn = std::conditional_t<(KernelGeom<V, P, CBC, GC, TuneColsStreamIn>::NW > 0), TransposedSide<TuneColsStreamIn>, TuneColsStreamIn>;
+        using TSColsOut = std::conditional_t<(KernelGeom<V, P, CBC, GC, TuneColsStreamOut>::NW > 0), TransposedSide<TuneColsStreamOut>, TuneColsStreamOut>;
+        if (tr_side) {
+            if (L.dir > 0) {
+                if (general) return launch_variant<V, P, CBC, GC, +1, true, TSCols>(L, stream);
+                if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, TSColsOut>(L, stream);
+                return launch_variant<V, P, CBC, GC, +1, false, TSCols>(L, stream);
+            }
+            if (general) return launch_variant<V, P, CBC, GC, -1, true, TSCols>(L, stream);
+            if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, TSColsIn>(L, stream);
+            return launch_variant<V, P, CBC, GC, -1, false, TSCols>(L, stream);
         }
         if (L.dir > 0) {
             if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneCols>(L, stream);

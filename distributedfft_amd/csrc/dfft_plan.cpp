@@ -244,6 +244,10 @@ struct dfft_plan_s {
     bool                    zy_on = false;
     unsigned                zy_ticket = 0;  // value of the control block's ticket counter when the next launch starts
     unsigned                zy_execs = 0, zy_cur = 0;  // executes that have used the stage; index of the current one (per-plane counters)
+    // overlapped forward plans: ONE launch of the stage over the whole slab that counts, per X-plane part, the column units whose results
+    // are in memory (dfft_zy.hip, SIG); the exchange stream waits for a part's count and ships it while the launch computes the next part
+    unsigned*               zy_part_done = nullptr;    // device: one counter per part (never reset: targets run on from execute to execute)
+    unsigned                zy_sig_execs = 0;
     bool                    zy_lazy = false;           // lazy-publish form of the one-launch kernel (un-packed launches; DFFT_ZY_LAZY=0: eager)
     bool                    zy_inv_rows_first = true;  // backward single-GPU plans: inverse stage rows first (DFFT_ZY_INV_ROWS_FIRST=0: columns first)
     int                     x_hints = 0;               // DFFT_X_VARIANT when the plan was created: FFT_HINT_HALF_PREFETCH / _EARLY_WAIT
@@ -476,7 +480,7 @@ static long long zy_phase_planes(const dfft_plan_s* p, long long nx) {
 //   backward: Y columns w -> w in place, or (packed) the packed receive layout in `other` -> w; then Z rows w -> dst
 // structure: 0 = the plan's direction; +1 on a backward plan = the inverse stage rows first (src = the hand-over buffer, w = the result buffer)
 static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w_plane, void* dst, void* other, bool packed, long long x0,
-                           long long nx, int structure = 0) {
+                           long long nx, int structure = 0, bool sig = false) {
     if (nx <= 0) return DFFT_OK;
     const void *twz = nullptr, *twy = nullptr;
     DFFT_TRY(get_twiddles((int)p->N[2], p->dtype, &twz));
@@ -523,6 +527,10 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     if (x0 == 0) p->zy_cur = p->zy_execs++;
     L.ticket_base = p->zy_ticket;
     L.done_base = p->zy_cur * producers;
+    if (sig) {  // whole-slab launch of the overlapped pipeline: count finished column units per X-plane part
+        L.part_done = p->zy_part_done;
+        L.part_planes = p->part_planes;
+    }
     if (p->zy_fault > 0 && ++p->zy_launches == (unsigned)p->zy_fault) L.fault = 1;  // test hook: this launch's consumers can never start
     p->zy_ticket += zy_tickets(L.n1, L.n2, L.dir, L.packed, L.nplanes, L.chunk);
     return check_launch(launch_zy(L, p->stream), "one-launch YZ stage");
@@ -567,10 +575,23 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
         const bool rccl = comm_is_async(p->comm);
         const int  K = (int)((p->sx.blk + p->part_planes - 1) / p->part_planes);
         const int  YK = p->ycuts;
+        // One launch of the YZ stage for ALL parts (round 6): the phases of the serial plan, no launch boundary and no 32-plane phase
+        // per part; the stage counts, per part, the column units whose results are in memory, and the exchange stream waits for a
+        // part's count (zy_part_wait_kernel) instead of an event behind a per-part launch.
+        const bool one_for_all = p->zy_on && p->zy_part_done != nullptr;
+        unsigned   sig_exec = 0, sig_units = 0;
+        if (one_for_all) {
+            unsigned producers = 0;
+            sig_units = zy_units_per_plane((int)n1, (int)n2, +1, 1, &producers) - producers;  // column units per plane
+            sig_exec = p->zy_sig_execs++;
+            DFFT_TRY(launch_zy_stage(p, zsrc, zdst, zl.plane, nullptr, p->buf2, true, 0, p->xs, 0, true));
+        }
         for (int k = 0; k < K; ++k) {
             long long x0, nx;
             part_range(p->xs, p->part_planes, k, &x0, &nx);
-            if (nx > 0 && p->zy_on) {  // Z rows + packing Y columns of the part in one launch
+            if (one_for_all) {
+                // (nothing to launch: the part is being computed by the launch above)
+            } else if (nx > 0 && p->zy_on) {  // Z rows + packing Y columns of the part in one launch
                 DFFT_TRY(launch_zy_stage(p, zsrc, zdst, zl.plane, nullptr, p->buf2, true, x0, nx));
             } else if (nx > 0) {
                 DFFT_TRY(fft_rows(zsrc, zdst, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1,
@@ -578,7 +599,16 @@ static int execute_forward(dfft_plan_s* p, bool sync) {
                 DFFT_TRY(launch_y(p, zdst, p->buf2, true, true, x0, nx, FFT_HINT_STREAM_OUT, &zl));
             }
             hipStream_t xs_ = rccl ? p->stream2 : p->stream;  // LOCAL: host-synchronising, same call sequence
-            if (rccl) {
+            if (rccl && one_for_all) {
+                // every execute adds nx * sig_units to the part's counter (all executes of a plan cut the same parts)
+                unsigned* errw = nullptr;
+                if (hipHostGetDevicePointer((void**)&errw, p->zy_err, 0) != hipSuccess) return fail(DFFT_EHIP, "one-launch YZ stage: no device pointer for the error word");
+                // (no event between the streams: the wait kernel polls the counter, and the count can only be reached by THIS execute's
+                // launch, which runs behind the previous execute's X pass on p->stream)
+                if (nx > 0)
+                    DFFT_TRY(check_launch(launch_zy_part_wait(p->zy_part_done + k, (sig_exec + 1u) * (unsigned)nx * sig_units, p->zy_ctl, errw, p->stream2),
+                                          "part wait of the one-launch YZ stage"));
+            } else if (rccl) {
                 DFFT_HIP_TRY(hipEventRecord(p->part_ev[k], p->stream));
                 DFFT_HIP_TRY(hipStreamWaitEvent(p->stream2, p->part_ev[k], 0));
             }
@@ -1378,7 +1408,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         const char* oe = getenv("DFFT_T0_ONE_LAUNCH");
         const long long ysub = p->sy.blk / std::max(1, p->ycuts);
         const bool      single_ok = !p->exch && (!p->wbuf || p->wl.pitch == n2 || DFFT_ZY_ROW_PITCH);
-        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % zy_col_threads((int)n1) == 0;  // even splits; a
+        const bool      multi_ok = p->exch && n0 % total_devices == 0 && n1 % total_devices == 0 && n1 >= 8 && ysub % zy_col_threads((int)n1, p->zy_lazy ? 1 : 0) == 0;  // even splits; a
                                    // destination block is a whole number of the column unit's strides (the threads of one column FFT)
         // Where the stage is used by itself (DFFT_T0_ONE_LAUNCH=0: never; =1: wherever the kernel exists on single-GPU plans; =all:
         // P > 1 plans too).  Round 3 used it for 512 x 512-point planes on a single GPU only; since round 4
@@ -1414,6 +1444,18 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                 p->zy_spin_polls = sp && atoll(sp) > 0 ? (unsigned)std::min(atoll(sp), 0xffffffffll) : (4u << 20);
                 const char* fe = getenv("DFFT_ZY_FAULT");
                 p->zy_fault = fe ? atoi(fe) : 0;
+                // overlapped forward plans: one launch for all parts (per-part counters of finished column units; the kernel addresses the
+                // packed layout of a slab with 32-bit byte offsets there).  DFFT_ZY_PARTS_ONE_LAUNCH=0: one launch per part (round 5's form).
+                const char* oa = getenv("DFFT_ZY_PARTS_ONE_LAUNCH");
+                const int   K = p->part_planes > 0 ? (int)((p->sx.blk + p->part_planes - 1) / p->part_planes) : 0;
+                if (p->exch && direction == DFFT_FORWARD && K > 0 && p->zy_lazy && !(oa && *oa == '0') && (size_t)p->max_count * elem_bytes(dtype) < ((size_t)1 << 32)) {
+                    if (hipMalloc((void**)&p->zy_part_done, (size_t)K * sizeof(unsigned)) != hipSuccess ||
+                        hipMemsetAsync(p->zy_part_done, 0, (size_t)K * sizeof(unsigned), p->stream) != hipSuccess || hipStreamSynchronize(p->stream) != hipSuccess) {
+                        (void)hipGetLastError();
+                        if (p->zy_part_done) (void)hipFree(p->zy_part_done);
+                        p->zy_part_done = nullptr;
+                    }
+                }
             } else {
                 (void)hipGetLastError();
             }
@@ -1771,10 +1813,10 @@ int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     const long long    nch = cp > 0 ? (p->xs + cp - 1) / cp : 1;
     const bool         fused = !(p->flags & DFFT_PLAN_UNFUSED);
     snprintf(buf, (size_t)len,
-             "pipeline=%s yz_stage=%s%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d tuned=%d x_variant=%s",
+             "pipeline=%s yz_stage=%s%s chunks=%lldx%lld handover=%s rotated_exchange_rows=%d overlap_parts=%lld ysub=%d parts_in_one_launch=%d tuned=%d x_variant=%s",
              (p->flags & DFFT_PLAN_NATURAL) ? "natural" : (fused ? "fused" : "unfused"),
              (p->zy_on && fused) ? "one-launch" : "two-launches-per-chunk", (p->zy_on && fused && p->zy_lazy) ? "-lazy" : "", nch, cp,
-             (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, p->w_kept >= 0 ? 1 : 0,
+             (fused && p->wbuf && !p->exch) ? "padded-buffer" : "bufferDev1", p->rot_elems, p->part_planes, p->ycuts, (p->zy_on && fused && p->zy_part_done) ? 1 : 0, p->w_kept >= 0 ? 1 : 0,
              (p->x_hints & FFT_HINT_HALF_PREFETCH) ? "half-prefetch" : ((p->x_hints & FFT_HINT_EARLY_WAIT) ? "early-wait" : "default"));
     return DFFT_OK;
 }
@@ -1877,6 +1919,7 @@ int dfft_plan_destroy(dfft_plan_t plan) {
     if (plan->wbuf) slab_free(plan->wbuf);
     if (plan->lbuf) hipFree(plan->lbuf);
     if (plan->zy_ctl) hipFree(plan->zy_ctl);
+    if (plan->zy_part_done) hipFree(plan->zy_part_done);
     if (plan->zy_err) hipHostFree(plan->zy_err);
     delete plan;
     return zy_rc;

@@ -60,13 +60,17 @@ struct ZyLaunch {
     int         fault;        // test hook: the consumers of this launch wait for one producer more than a plane has
     unsigned*   err_host;     // device pointer of a pinned host word: written with ZY_ERR_* when the launch gives up
     unsigned    spin_polls;   // bound of a consumer's wait, in polls of its plane's counter (1-3 us each)
+    unsigned*   part_done;    // != nullptr (forward packed lazy launches): per-part counters of finished column units, part = (plane - plane0) / part_planes
+    long long   part_planes;
 };
 
 bool       zy_supported(int dtype, int n1, int n2);
-int        zy_col_threads(int n1);
+int        zy_col_threads(int n1, int lazy);
 long long  zy_grid();
 unsigned   zy_units_per_plane(int n1, int n2, int dir, int packed, unsigned* producers);
 unsigned   zy_tickets(int n1, int n2, int dir, int packed, long long nplanes, long long chunk);
 hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream);
+// exchange stream: wait until *ctr has reached target (the column units of one X-plane part of a part_done launch)
+hipError_t launch_zy_part_wait(const unsigned* ctr, unsigned target, const ZyCtl* ctl, unsigned* err_host, hipStream_t stream);
 
 }  // namespace dfft

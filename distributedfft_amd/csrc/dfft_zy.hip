@@ -39,6 +39,11 @@ namespace dfft {
 namespace {
 
 typedef unsigned zy_u32x4 __attribute__((ext_vector_type(4)));
+// cache policy of the send-buffer stores of SIG launches: sc1 (16, write-through) | nt (2, streaming: the send buffer is not read again by
+// this device and must not push the Z -> Y intermediate out of the Infinity Cache).  -DDFFT_ZY_SIG_AUX=16: sc1 alone (A/B)
+#ifndef DFFT_ZY_SIG_AUX
+#define DFFT_ZY_SIG_AUX 18
+#endif
 #define DFFT_ZY_AGENT __HIP_MEMORY_SCOPE_AGENT
 
 // DIR = +1: producers = Z rows (src -> w), consumers = Y columns (w in place)
@@ -65,11 +70,18 @@ template <class PY, bool PACK> struct ZyTile {
 // commute, and columns-first makes the column units READ the hand-over buffer from HBM in 128-byte pieces one row apart (the inverse X pass
 // has just written all of it; the counters show 40 % more read latency behind the L2 than in the forward stage, profiles/r05/README.md
 // section 4) where rows-first reads whole rows from HBM and leaves the strided side to the cache-resident chunk, like the forward stage.
-template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR>
+// SIG (round 6; forward packed lazy launches of the overlapped pipeline): the launch covers the WHOLE slab and tells the exchange stream
+// when an X-plane part of the send buffer is complete -- every column unit, once its stores have left the CU (they are write-through
+// sc1 buffer stores here, so "left the CU" means "in memory", like the Z -> Y hand-over), adds one to its part's counter
+// part_done[(plane - plane0) / part_planes]; a one-wave kernel on the exchange stream (zy_part_wait_kernel) waits for the count of
+// the part's column units and the part's exchange follows it in stream order.  One launch, the phases of the serial plan, no
+// per-part launch boundaries.
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR, bool SIG = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(ZyTile<PY, PACK>::THREADS, ZyTile<PY, PACK>::THREADS), amdgpu_waves_per_eu(1)))
 zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const double2* __restrict__ twz, const double2* __restrict__ twy,
                 long long src_plane, long long w_plane, long long dst_plane, unsigned plane0, unsigned nplanes, unsigned chunk,
-                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls, unsigned need
+                unsigned ticket_base, unsigned done_base, AxisMap pk, long long pk_plane, RotMap rm, unsigned* err_host, unsigned spin_polls, unsigned need,
+                unsigned* part_done, unsigned part_planes
 #if DFFT_ZY_ROW_PITCH
                 , unsigned wpitch
 #endif
@@ -81,6 +93,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     // 256-thread workgroup -- one register set sized for the larger kind serves both kinds of unit
     constexpr int N2 = PZ::N, N1 = PY::N, EZ = PZ::E, EY = PY::E, E = EZ > EY ? EZ : EY, TZ = PZ::T, TY = PY::T;
     static_assert(TZ <= 64 && 64 % TZ == 0 && THREADS % TZ == 0, "rows: one FFT inside one wavefront");
+    static_assert(!SIG || (PACK && LAZY && DIR > 0 && SIGN > 0), "part signalling: forward packed lazy launches");
     constexpr int GR = THREADS / TZ;  // rows per row unit
     static_assert(N1 % GR == 0 && N2 % CB == 0, "a plane must split into whole units");
     constexpr unsigned UZ = N1 / GR, UY = N2 / CB;
@@ -202,9 +215,11 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     };
     // packed side (PACK): point jy + TY k of a column lies in block (TY k) / pk.blk of the map -- the launcher guarantees
     // pk.blk % TY == 0, so the block term is wave-uniform per k (computed once) -- plus one per-thread term and the tile's base
-    // 768 points on 12 x 64 threads (config 4: destination blocks of 96 rows at P = 8): blocks are multiples of 32 rows, not of the 64
-    // a wavefront's threads span, so the lower and the upper half of the threads of a column each get a uniform term of their own
-    constexpr bool PK2 = PACK && PY::N == 768 && TY == 64;
+    // 64 threads per column (512 and 768 points): destination blocks are multiples of 32 rows (config 4: 96 rows at P = 8; the 32-row Y
+    // sub-blocks of the overlapped pipeline of 512^3 at P = 8), not of the 64 a column's threads span, so the lower and the upper half of
+    // the threads of a column each get a uniform term of their own (the same numbers when a block is whole 64-row strides)
+    // (the eager 512-point kernels -- the tests' bit-identity reference -- have no registers for the second table: whole 64-row strides there)
+    constexpr bool PK2 = PACK && TY == 64 && (LAZY || PY::N == 768);
     unsigned       pk_uni[PACK ? EY : 1], pk_uni1[PK2 ? EY : 1];
     if constexpr (PACK) {
 #pragma unroll
@@ -278,7 +293,18 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         }
     };
     auto store_cols = [&](unsigned plane, unsigned un, const V* v) {
-        if constexpr (ROWS_PRODUCE && PACK) {
+        if constexpr (ROWS_PRODUCE && PACK && SIG) {
+            // the send buffer, written through (sc1): what the part counter announces has to be in memory, not in this XCD's L2.  Base
+            // of the buffer descriptor: the tile's plane and (rotated) column, wave-uniform; per thread a 32-bit byte offset (the
+            // launcher checks that the packed layout of one slab stays below 4 GiB)
+            int col = (int)(un * CB);
+            if (rm.rot != 0) col = (col + rm.rot * (int)(plane + (unsigned)rm.a0)) & rm.mask;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + (long long)plane * pk_plane + col), 0, (int)0xffffffffu, 0x00020000);
+            const unsigned               thr = (unsigned)pk_thr;
+#pragma unroll
+            for (int k = 0; k < EY; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(zy_u32x4, v[k]), rs, (int)((thr + pk_off(k)) * 16u), 0, DFFT_ZY_SIG_AUX);
+        } else if constexpr (ROWS_PRODUCE && PACK) {
             V* op = dst + pk_base(plane, un);  // the send buffer: not read again by this device, streamed out
 #pragma unroll
             for (int k = 0; k < EY; ++k) gstore<true>(op + pk_off(k), v[k]);
@@ -376,9 +402,18 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
         // unit after next polled.  After the stores nothing waits, so they drain underneath the next unit.
         constexpr unsigned NOPLANE = 0xffffffffu;
         unsigned           pend = NOPLANE;  // plane of a producer unit whose results are stored but not yet published
+        unsigned           pend_sig = NOPLANE;  // SIG: part of a column unit whose results are stored but not yet counted
         auto               flush = [&]() {
             if (pend != NOPLANE) publish(pend);
             pend = NOPLANE;
+            if constexpr (SIG) {
+                if (pend_sig != NOPLANE) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: the unit's results are in memory
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(&part_done[pend_sig], 1u, __ATOMIC_RELAXED, DFFT_ZY_AGENT);
+                }
+                pend_sig = NOPLANE;
+            }
         };
         bool nxt_ok = false;  // the dependency of nxt is known to be satisfied (polled at an earlier quiet point)
         while (cur.ticket < total) {
@@ -407,6 +442,7 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
                 nn_ok = nn.kind != CONS || ready(nn, false);
                 store_unit(cur, v);
                 if (cur.kind == PROD) pend = cur.plane;
+                else if constexpr (SIG) pend_sig = (cur.plane - plane0) / part_planes;
             } else {
                 nn = decode(share(t2));
             }
@@ -426,14 +462,14 @@ zy_chunk_kernel(const double2* src, double2* w, double2* dst, ZyCtl* ctl, const 
     }
 }
 
-template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
+template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = DIR, bool SIG = false> hipError_t launch_zy_t(const ZyLaunch& L, hipStream_t stream) {
     constexpr int    CB = ZyTile<PY, PACK>::CB, THREADS = ZyTile<PY, PACK>::THREADS, GR = THREADS / PZ::T;
     constexpr unsigned UA = DIR > 0 ? (unsigned)(PY::N / GR) : (unsigned)(PZ::N / CB);  // producer units per plane, as in the kernel
     constexpr size_t ROW_BYTES = (size_t)GR * (PZ::N + PZ::N / 8) * sizeof(double2), COL_BYTES = (size_t)PY::N * CB * sizeof(double2);
     constexpr size_t TW_BYTES = (TwTotal<PZ, true>::value > 16 ? (size_t)PZ::N * sizeof(double2) : 0) + (TwTotal<PY, true>::value > 16 ? (size_t)PY::N * sizeof(double2) : 0);
     constexpr size_t LDS_BYTES = 64 + TW_BYTES + (ROW_BYTES > COL_BYTES ? ROW_BYTES : COL_BYTES);
     static_assert(LDS_BYTES <= 160 * 1024, "a unit and the twiddle tables must fit the LDS of a CU");
-    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY, SIGN>;
+    auto             kern = zy_chunk_kernel<PZ, PY, DIR, PACK, LAZY, SIGN, SIG>;
     static std::atomic<bool> attr_set[64];
     static std::mutex        setup_mutex;
     int                      dev = 0;
@@ -446,7 +482,8 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = 
         if (e != hipSuccess) return e;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    constexpr int PK_GRAIN = (PY::N == 768 && PY::T == 64) ? 32 : PY::T;  // (PK2 in the kernel)
+    constexpr int PK_GRAIN = (PY::T == 64 && (LAZY || PY::N == 768)) ? 32 : PY::T;  // (PK2 in the kernel)
+    if (SIG && (!L.part_done || L.part_planes <= 0)) return hipErrorInvalidValue;
     if (PACK && (L.pk.blk <= 0 || L.pk.blk % PK_GRAIN != 0 || L.pk.last_delta != 0)) return hipErrorInvalidValue;
     // one workgroup per CU (the shape measured in round 2; a second one per CU gained nothing -- nor do two or three of the
     // 256-thread workgroups of 256-point Y axes, profiles/r03/experiments/variant_ab_256.log)
@@ -454,7 +491,7 @@ template <class PZ, class PY, int DIR, bool PACK, bool LAZY = false, int SIGN = 
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), LDS_BYTES, stream, (const double2*)L.src, (double2*)L.w, (double2*)L.dst, L.ctl,
                        (const double2*)L.twz, (const double2*)L.twy, L.src_plane, L.w_plane, L.dst_plane, (unsigned)L.plane0, (unsigned)L.nplanes,
-                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls, UA + (L.fault ? 1u : 0u)
+                       (unsigned)L.chunk, L.ticket_base, L.done_base, L.pk, L.pk_plane, L.rot, L.err_host, L.spin_polls, UA + (L.fault ? 1u : 0u), L.part_done, (unsigned)L.part_planes
 #if DFFT_ZY_ROW_PITCH
                        , (unsigned)L.w_pitch
 #endif
@@ -487,10 +524,38 @@ ZyGeom zy_geom(int n1, int n2, int packed) {
 
 }  // namespace
 
+// The exchange stream's side of SIG launches: one wave that returns when the part's counter has reached `target` (wrapping compare),
+// the stage has given up (sticky error word of the control block), or the time limit has passed (then it raises the plan's error word
+// itself: the exchange behind it ships an incomplete part, and the host reports the execute as invalid like any other failure of the stage).
+namespace {
+__global__ void zy_part_wait_kernel(const unsigned* ctr, unsigned target, const ZyCtl* ctl, unsigned* err_host, unsigned long long limit_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();  // 100 MHz
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, DFFT_ZY_AGENT) - target) < 0) {
+        if (__hip_atomic_load(&ctl->error, __ATOMIC_RELAXED, DFFT_ZY_AGENT) != 0u) return;
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > limit_ticks) {
+            __hip_atomic_store(err_host, (unsigned)ZY_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+}  // namespace
+hipError_t launch_zy_part_wait(const unsigned* ctr, unsigned target, const ZyCtl* ctl, unsigned* err_host, hipStream_t stream) {
+    static const unsigned long long limit = [] {
+        const char*  e = getenv("DFFT_ZY_PART_TIMEOUT_S");
+        const double s = e && atof(e) > 0 ? atof(e) : 30.0;
+        return (unsigned long long)(s * 1e8);
+    }();
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(zy_part_wait_kernel, dim3(1), dim3(64), 0, stream, ctr, target, ctl, err_host, limit);
+    return hipGetLastError();
+}
+
 // fp64; Y axis of 256, 512 or (round 5) 768 points, Z axis of 256 or 512 points
 bool zy_supported(int dtype, int n1, int n2) { return dtype == F64 && (n1 == 256 || n1 == 512 || (n1 == 768 && n2 == 512)) && (n2 == 256 || n2 == 512); }
 // threads that share one column FFT of the Y axis: a destination block of the packed layout must be a whole number of them
-int zy_col_threads(int n1) { return n1 == 768 ? 32 : n1 / 8; }  // (768 points: either column plan takes destination blocks of whole 32 rows)
+int zy_col_threads(int n1, int lazy) { return (n1 == 768 || (n1 == 512 && lazy)) ? 32 : n1 / 8; }  // (64 threads per column -- 512 (lazy form), 768 points: destination blocks of whole 32 rows, PK2)
 
 // workgroups per launch: one per CU.  Every workgroup takes tickets until it sees one past the end, holding two ahead, so a launch
 // advances the ticket counter by its item count + 2 per workgroup: zy_tickets() is what the host adds to its running ticket base.
@@ -516,6 +581,8 @@ hipError_t launch_zy(const ZyLaunch& L, hipStream_t stream) {
     if (L.n2 == NZ && L.n1 == NY) {                                                                                             \
         if (L.lazy && !L.packed && L.dir > 0 && L.sign < 0) return launch_zy_t<PZ_, PY_, +1, false, true, -1>(L, stream);                         \
         if (L.sign != 0 && L.sign != L.dir) return hipErrorInvalidValue;                                                                        \
+        if (L.part_done && !(L.lazy && L.packed && L.dir > 0)) return hipErrorInvalidValue;                                                     \
+        if (L.part_done) return launch_zy_t<PZ_, PY_, +1, true, true, +1, true>(L, stream);                                                     \
         if (L.lazy && L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true, true>(L, stream); \
         if (L.lazy) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, false, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, false, true>(L, stream); \
         if (L.packed) return L.dir > 0 ? launch_zy_t<PZ_, PY_, +1, true>(L, stream) : launch_zy_t<PZ_, PY_, -1, true>(L, stream); \

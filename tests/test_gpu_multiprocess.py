@@ -19,11 +19,23 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A port p with p AND p + 1 free: launched through MASTER_PORT (torchrun's variable) the library's rendezvous listens on
+    MASTER_PORT + 1, off torchrun's own store port (dfft_bootstrap.cpp) -- checking p alone left that one to chance (seen once in round 6:
+    'bind/listen on 127.0.0.1:38510: Address already in use')."""
+    for _ in range(64):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s2 = socket.socket()
+        try:
+            s2.bind(("127.0.0.1", p + 1))
+        except OSError:
+            continue
+        finally:
+            s2.close()
+            s.close()
+        return p
+    raise RuntimeError("no pair of free ports")
 
 
 def _launch(world, argv, extra_env=None, timeout=300, expect_rc=0):

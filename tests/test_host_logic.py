@@ -340,7 +340,9 @@ def test_headline_kernels_do_not_spill():
     # the one-launch YZ stage (csrc/dfft_zy.hip; the headline's t0): every instantiation, and the lazy-publish kernels with room to
     # spare (they keep the products of their twiddle powers out of the unit loop's invariants: 192-200 registers)
     rows = kr.zy_table()
-    assert len(rows) == 45, len(rows)   # 5 plane shapes x (2 directions x packed / un-packed x eager / lazy + the inverse stage rows first)
+    # 5 plane shapes x (2 directions x packed / un-packed x eager / lazy + the inverse stage rows first + the forward packed lazy
+    # form that serves all parts of the overlapped pipeline in one launch)
+    assert len(rows) == 50, len(rows)
     for tag, vgpr, scratch, _ in rows:
         # the eager-publish kernels are the bit-identity reference of the tests, not a shipped path; the packed 768-point ones (two
         # uniform offset tables, 12 + 12 points) keep up to 80 bytes in scratch -- every lazy-publish kernel, which is what plans run, none

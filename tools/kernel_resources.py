@@ -82,7 +82,7 @@ def zy_table():
         name = m.group(1)
         body = asm[m.start():asm.index(".end_amdhsa_kernel", m.start())]
         lens = re.findall(r"ILi(\d+)ELi(?:8|12|24)E", name)  # Plan<N, 8 | 12 | 24, ...> of the Z and (when different) Y axis
-        mm = re.search(r"Li(n?1)ELb([01])ELb([01])E(?:Li(n?1)E)?", name)
+        mm = re.search(r"Li(n?1)ELb([01])ELb([01])E(?:Li(n?1)E)?(?:Lb([01])E)?", name)
         if not lens or not mm:
             continue
         nz, ny = lens[0], lens[-1]
@@ -91,7 +91,8 @@ def zy_table():
             f = re.search(rf"\.amdhsa_{key} (\d+)", body)
             return int(f.group(1)) if f else 0
         tag = (f"f64 zy_chunk_kernel Z={nz} Y={ny} dir={'-1' if mm.group(1) == 'n1' else '1'} packed={mm.group(2)} "
-               f"{'lazy' if mm.group(3) == '1' else 'eager'}{' inverse-rows-first' if mm.group(4) == 'n1' and mm.group(1) == '1' else ''}")
+               f"{'lazy' if mm.group(3) == '1' else 'eager'}{' inverse-rows-first' if mm.group(4) == 'n1' and mm.group(1) == '1' else ''}"
+               f"{' all-parts (counts finished column units per exchange part)' if mm.group(5) == '1' else ''}")
         rows.append((tag, field("next_free_vgpr"), field("private_segment_fixed_size"), field("group_segment_fixed_size")))
     return rows
 
