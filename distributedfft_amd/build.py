@@ -143,6 +143,11 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
         if force or _newer(exe, [bt_src, lib] + hdrs):
             _run([HIPCC] + COMMON + ["-x", "hip", f"-DBATCH_DIM={dim}", str(bt_src), "-x", "none", "-o", str(exe), "-L" + str(LIBDIR),
                                      "-ldfft_mi355x", "-lpthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(ROCM / "lib")])
+    # message-passing litmus of the hand-offs the one-launch YZ stage relies on (tools/zy_litmus.hip; tests/test_gpu_litmus.py runs it)
+    lit = LIBDIR / "zy_litmus"
+    lit_src = ROOT / "tools" / "zy_litmus.hip"
+    if lit_src.exists() and (force or _newer(lit, [lit_src])):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", str(lit_src), "-o", str(lit)])
     return lib
 
 
