@@ -130,12 +130,13 @@ def cpu_baseline():
 
 
 def is_forward_zy_kernel(name: str) -> bool:
-    """rocprofv3 kernel name of the FORWARD one-launch YZ stage, any variant: zy_chunk_kernel<PZ, PY, DIR = 1, PACK, LAZY[, SIGN = 1]>.
+    """rocprofv3 kernel name of the FORWARD one-launch YZ stage, any variant: zy_chunk_kernel<PZ, PY, DIR = 1, PACK, LAZY[, SIGN = 1[, SIG]]>.
     (The inverse stage run rows first is <..., 1, false, true, -1>: same structure, other transform -- not t0 of a forward execute.  A
     template parameter added to the kernel once made this test miss every launch and the bench line's roofline.traffic came out null:
     tests/test_host_logic.py pins the names.)"""
     import re
-    return "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*(, 1)?>", name) is not None
+    # (round 6 added SIG behind SIGN -- and the pattern missed every launch again until the names below were taken from a real trace)
+    return "zy_chunk_kernel" in name and re.search(r">, 1(, (true|false))*(, 1(, (true|false))*)?>", name) is not None
 
 
 def library_sha256() -> str | None:
@@ -167,6 +168,31 @@ def measured_traffic(key: str, kernel: str):
         return ent[kernel]["hbm_bytes_per_launch"], ent.get("source", "profiles/")
     except Exception as e:
         return None, f"profiles/hbm_traffic.json unreadable: {e}"
+
+
+# What the memory system of this chip delivers to plain streaming kernels (tools/l2probe.hip on MI355X: persistent kernel, one 512-thread
+# workgroup per CU, 16 B per lane, non-temporal; profiles/r05/experiments/l2probe_time.log) -- 2 GiB buffers in HBM / 64 MiB cache-resident
+STREAM_GBS = {"read_hbm": 7020.0, "read_cache_resident": 7520.0, "write_hbm": 5570.0, "write_cache_resident": 5820.0,
+              "copy_hbm": 5780.0, "copy_cache_resident": 6400.0}
+
+
+def fabric_block(t0_bytes, t0_s, x_bytes, x_s):
+    """Counter bytes (FETCH_SIZE x 2 + WRITE_SIZE: what crosses the L2 <-> fabric boundary, Infinity-Cache hits included) over launch
+    time, next to the stream rates the same fabric gives plain kernels: the SURVEY 8(d) fraction charges the t0 launch 2 S N/P bytes,
+    but the launch moves twice that through the fabric (Z -> Y intermediate written to and read back from the Infinity Cache), so a
+    'frac' of ~0.46 of 8 TB/s is ~7.4 TB/s of fabric traffic -- at the read-stream rate of the chip."""
+    def one(b, t):
+        if b is None or not t:
+            return None
+        r = b / t / 1e9
+        return {"bytes": b, "GB/s": round(r, 1), "over_read_stream_hbm": round(r / STREAM_GBS["read_hbm"], 3),
+                "over_read_stream_cache_resident": round(r / STREAM_GBS["read_cache_resident"], 3),
+                "over_copy_hbm": round(r / STREAM_GBS["copy_hbm"], 3), "over_copy_cache_resident": round(r / STREAM_GBS["copy_cache_resident"], 3)}
+    out = {"stream_rates_GB/s": STREAM_GBS, "stream_rates_source": "tools/l2probe.hip, profiles/r05/experiments/l2probe_time.log",
+           "t0_launch": one(t0_bytes, t0_s), "x_pass": one(x_bytes, x_s)}
+    if t0_bytes is not None and x_bytes is not None and t0_s and x_s:
+        out["transform"] = one(t0_bytes + x_bytes, t0_s + x_s)
+    return out
 
 
 def live_traffic(args, nchunks: int):
@@ -664,6 +690,7 @@ def main():
                         "device_copy_of_same_bytes_GB/s": None if copy_gbs is None else round(copy_gbs, 1),
                         "x_pass": xroof,
                         "local_pipeline": xroof.get("local_pipeline")}
+                roof["fabric"] = fabric_block(zt, t0_s, xroof.get("traffic"), x_s)
         if kern is not None:
             k = int(np.argmax(kern))
             ach = local_bytes / kern[k] / 1e9

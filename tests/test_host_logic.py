@@ -362,7 +362,9 @@ def test_bench_recognises_the_forward_yz_stage_in_rocprof_names():
     pre = "void dfft::(anonymous namespace)::zy_chunk_kernel<dfft::Plan<512, 8, 8, 8, 8>, dfft::Plan<512, 8, 8, 8, 8>, "
     post = ">(HIP_vector_type<double, 2u> const*, HIP_vector_type<double, 2u>*)"
     for args, want in (("1, false, true, 1", True), ("1, true, true, 1", True), ("1, false, false, 1", True), ("1, false, true", True),
-                       ("1, false, true, -1", False),      # the inverse stage run rows first
-                       ("-1, false, true, -1", False), ("-1, true, true, -1", False)):
+                       ("1, false, true, 1, false", True),   # round 6: as rocprofv3 prints the headline's t0 (profiles/r06 trace)
+                       ("1, true, true, 1, true", True),     # ... and the launch that serves all parts of the overlapped pipeline
+                       ("1, false, true, -1", False), ("1, false, true, -1, false", False),      # the inverse stage run rows first
+                       ("-1, false, true, -1", False), ("-1, true, true, -1", False), ("-1, true, true, -1, false", False)):
         assert b.is_forward_zy_kernel(pre + args + post) is want, args
     assert not b.is_forward_zy_kernel("void dfft::fft_tiles_kernel<HIP_vector_type<double, 2u>, dfft::Plan<512, 8, 8, 8, 8>, 8, 1, 1, false, dfft::TuneTransposedStore>(...)")

@@ -27,10 +27,11 @@ DST = ROOT / "profiles" / ROUND
 
 def short(name: str) -> str:
     m = re.search(r"fft_tiles_kernel<(.*?), dfft::Plan<(\d+), (\d+)[^>]*>, (\d+), (\d+), (-?\d+), (true|false), dfft::(\w+)>", name)
-    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)(?:, (true|false))?(?:, (true|false))?(?:, (-?\d+))?>", name)
+    mz = re.search(r"zy_chunk_kernel<dfft::Plan<(\d+),[^>]*>, dfft::Plan<(\d+),[^>]*>, (-?\d+)(?:, (true|false))?(?:, (true|false))?(?:, (-?\d+))?(?:, (true|false))?>", name)
     if mz:  # t0 as one persistent launch (dfft_zy.hip)
         return (f"zy_chunk_kernel f64 NZ={mz.group(1)} NY={mz.group(2)} dir={mz.group(3)}{' packed' if mz.group(4) == 'true' else ''}"
-                f"{' lazy-publish' if mz.group(5) == 'true' else ''}{' inverse-rows-first' if mz.group(6) and mz.group(6) != mz.group(3) else ''} (one-launch YZ stage)")
+                f"{' lazy-publish' if mz.group(5) == 'true' else ''}{' inverse-rows-first' if mz.group(6) and mz.group(6) != mz.group(3) else ''}"
+                f"{' all-parts' if mz.group(7) == 'true' else ''} (one-launch YZ stage)")
     if not m:
         m2 = re.search(r"fft_generic_kernel<(.*?), (-?\d+)>", name)
         if m2:
