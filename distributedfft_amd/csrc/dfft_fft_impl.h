@@ -1138,15 +1138,27 @@ fft_dual_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
 // wave-uniform one, so the stage needs no table of its own; the NH-point stages read the even entries of the N-point table
 // from an LDS copy.  Fast path only (no ragged tile, no uneven slab, natural or packed maps whose blocks are multiples of
 // T / 2 T points); the transposing store of the forward X pass stays on fft_dual_tiles_kernel.
-template <class V, class PH, int CB> struct Dif2Geom {
+// TOUT (round 6): the OUTPUT side is the transposed one ([..][z][kx], kx fastest: the forward X pass).  The two half transforms leave
+// X[2m] and X[2m + 1] -- neighbours in kx -- in the registers of one thread; they are staged through an LDS image of [scalar column][kx]
+// rows, CB / 2 columns at a time (the image of all CB columns of an N-point tile is twice the LDS), and stored in linear order, 1 KiB
+// runs per wave instruction, like the staged store of fft_tiles_kernel.  Against the paired half-line tiles of fft_dual_tiles_kernel
+// (the 2048-point X pass until round 6): full 128-byte lines on the load side without pairing tiles, two workgroup barriers per half
+// transform instead of six (the second exchange is wave-owned, the third thread-local), 8 per 256 KiB of data instead of 16.
+template <class V, class PH, int CB, bool TOUT = false> struct Dif2Geom {
     using W = typename VecTraits<V>::W;
+    static constexpr int    LANES = VecTraits<V>::LANES, OPAD = LANES == 2 ? 2 : 1, N = 2 * PH::N;
     static constexpr size_t TW_BYTES = ((size_t)2 * PH::N * sizeof(W) + 15) / 16 * 16;  // the whole N-point table
-    static constexpr size_t LDS_BYTES = TW_BYTES + (size_t)PH::N * CB * sizeof(V);
+    static constexpr size_t TILE_BYTES = (size_t)PH::N * CB * sizeof(V);
+    // image of CB / 2 columns: padded rows where they fit next to the table, else rows of N rotated by their index (fft_dual_tiles_kernel)
+    static constexpr bool   PADROW = TW_BYTES + (size_t)(CB / 2) * LANES * (N + OPAD) * sizeof(W) <= 160 * 1024;
+    static constexpr int    ROW = PADROW ? N + OPAD : N;
+    static constexpr size_t IMG_BYTES = TOUT ? (size_t)(CB / 2) * LANES * ROW * sizeof(W) : 0;
+    static constexpr size_t LDS_BYTES = TW_BYTES + (TILE_BYTES > IMG_BYTES ? TILE_BYTES : IMG_BYTES);
     static_assert(LDS_BYTES <= 160 * 1024, "DIF-split tiles: half tile + twiddle table must fit the CU's LDS");
 };
 // BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
 // which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0>
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0, bool TOUT = false>
 __global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(1)))
 fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
@@ -1154,11 +1166,14 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
-    constexpr int E = PH::E, T = PH::T, GT = CB * T, NH = PH::N, N = 2 * NH;
+    constexpr int E = PH::E, T = PH::T, GT = CB * T, NH = PH::N, N = 2 * NH, LANES = VT::LANES;
     static_assert(PH::S > 1 && E * T == NH && GT <= 1024, "DIF-split tiles: multi-stage half plan, one workgroup per tile");
+    static_assert(!TOUT || (BOUT == false && (ROT == 0 || ROT == 2) && CB % 2 == 0 && ((CB / 2) * (N / LANES)) % GT == 0 && (N / LANES) % GT == 0),
+                  "staged transposed output: rotation per point on the input side only, image phases that split evenly over the workgroup");
+    using DG = Dif2Geom<V, PH, CB, TOUT>;
     extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
     W* ldstw = reinterpret_cast<W*>(dfft_smem);  // N entries; the NH-point stages use every second one
-    V* lds = reinterpret_cast<V*>(dfft_smem + Dif2Geom<V, PH, CB>::TW_BYTES);
+    V* lds = reinterpret_cast<V*>(dfft_smem + DG::TW_BYTES);
     constexpr int NWV = owned_waves<V, CB, T>();
     const int tid = threadIdx.x, c = tid % CB, j = tile_j<CB, NWV>(tid);
 #if DFFT_TW_STAGE_MAJOR
@@ -1310,6 +1325,101 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
         }
     }
 #else
+    if constexpr (TOUT) {
+        // Software pipeline over tiles: the next tile's loads are issued as soon as the second image phase has taken the last results out
+        // of the registers -- in front of that phase's stores, so the wait for the loaded points (one vmcnt for loads and stores) lets
+        // those stores drain underneath the next tile's first stage instead of in front of it.
+        constexpr int CH = CB / 2, ON = N / LANES, ROW = DG::ROW;
+        auto img_at = [](int col, int e) -> int {  // element e (units of W) of scalar column col of the phase
+            if constexpr (DG::PADROW) return col * ROW + e;
+            else return col * N + ((e + LANES * col) & (N - 1));
+        };
+        W*        img = reinterpret_cast<W*>(lds);
+        const int mine = c / CH, cl = c - mine * CH;
+        V         v0[E], v1[E];
+        // Loads through buffer descriptors: one 32-bit per-thread offset (plus the per-point rotation) and a wave-uniform scalar offset
+        // k * step per point instead of a 64-bit address register pair per load -- with 2 E loads in flight next to the image reads of the
+        // second phase the flat form went 276-308 bytes over the 256 registers.  Two descriptors, one per half of the points (the slab
+        // side of config 5's X pass spans 4 GiB per rank at P = 8, 8 GiB at P = 4; the launcher checks that a half stays below 4 GiB).
+        static_assert(!BIN, "staged transposed output: single-block input map (offsets kk * step)");
+        const unsigned thr16 = (unsigned)((long long)j * imap.stride + (long long)c * imap.cstride) * 16u;
+        auto load_tile = [&](unsigned t) {
+            const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+            const int      cbi = (int)(b * CB);
+            const char*    row0 = reinterpret_cast<const char*>(in + (long long)a * itile.a_stride);  // column 0 of the tile's slice
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)row0, 0, (int)0xffffffffu, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(row0 + (long long)E * istep * 16), 0, (int)0xffffffffu, 0x00020000);
+            int rj = ROT == 2 ? (rm.rot * j) & rm.mask : 0;
+            if constexpr (ROT == 2) asm volatile("" : "+v"(rj));  // this tile's value: hoisted, the 2 E per-point rotations would live in registers
+            const int rot_t = ROT == 2 ? (rm.rot * T) & rm.mask : 0;
+            const unsigned col16 = (unsigned)((long long)cbi * itile.b_stride) * 16u;  // un-rotated: the tile's first column
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                unsigned o0 = thr16 + col16, o1 = o0;
+                if constexpr (ROT == 2) {  // rotated rows of the receive buffer, per point: plane j + T kk starts rot * plane further on in its row
+                    o0 = thr16 + (unsigned)((cbi + rj + k * rot_t) & rm.mask) * 16u;
+                    o1 = thr16 + (unsigned)((cbi + rj + (k + E) * rot_t) & rm.mask) * 16u;
+                }
+                const int so = (int)((unsigned)k * (unsigned)istep * 16u);  // wave-uniform
+                v0[k] = VT::from_g(__builtin_bit_cast(GV, __builtin_amdgcn_raw_buffer_load_b128(rs0, (int)o0, so, NTL ? 2 : 0)));
+                v1[k] = VT::from_g(__builtin_bit_cast(GV, __builtin_amdgcn_raw_buffer_load_b128(rs1, (int)o1, so, NTL ? 2 : 0)));
+            }
+        };
+        // -DDFFT_DIF2_TOUT_PIPE=1 builds the software pipeline described above: measured and NOT adopted (round 6) -- with the next tile's 2 E
+        // points in flight next to the second phase's image reads the kernel needs 270-300 bytes of scratch (flat or buffer loads alike)
+#ifndef DFFT_DIF2_TOUT_PIPE
+#define DFFT_DIF2_TOUT_PIPE 0
+#endif
+        unsigned t = blockIdx.x;
+        if (DFFT_DIF2_TOUT_PIPE && t < ntiles) load_tile(t);
+        for (; t < ntiles; t += gridDim.x) {
+            const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+            if (!DFFT_DIF2_TOUT_PIPE) load_tile(t);
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const V sum = cadd(v0[k], v1[k]);
+                const V dif = csub(v0[k], v1[k]);
+                v0[k] = sum;
+                v1[k] = cmul(dif, fst[T * k]);  // W_N^{j + T k}
+            }
+            run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, TWS_RUN, NWV>(v0, ldstw, lds, j, c);
+            run_stages<V, PH, 0, DIR, CB, false, false, TW_LDS, false, 1, TWS_RUN, NWV>(v1, ldstw, lds, j, c);
+            // thread (j, c) now holds X[2 m] in v0[k] and X[2 m + 1] in v1[k], m = j + T k, of column (pair) c: stage them through the
+            // image of [scalar column][kx] rows, CH = CB / 2 columns per phase, and store the image in linear order
+            GV* ot = out + (long long)a * otile.a_stride + (long long)(b * CB) * otile.b_stride;  // omap.cstride: distance between SCALAR columns
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                __syncthreads();  // the last exchange / the previous phase's image is no longer read
+                if (mine == ph) {
+#pragma unroll
+                    for (int k = 0; k < E; ++k) {
+                        const V a0 = cscale(v0[k], sc), a1 = cscale(v1[k], sc);
+#pragma unroll
+                        for (int l = 0; l < LANES; ++l) {
+                            const W e0 = VT::lane(a0, l), e1 = VT::lane(a1, l);
+                            if constexpr (LANES == 2 && DG::PADROW) {  // two 8-byte neighbours in kx: one 16-byte write
+                                *reinterpret_cast<f32x4*>(img + img_at(cl * LANES + l, 2 * (j + T * k))) = f32x4{e0.x, e0.y, e1.x, e1.y};
+                            } else {
+                                img[img_at(cl * LANES + l, 2 * (j + T * k))] = e0;
+                                img[img_at(cl * LANES + l, 2 * (j + T * k) + 1)] = e1;
+                            }
+                        }
+                    }
+                }
+                if (DFFT_DIF2_TOUT_PIPE && ph == 1 && t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // every result has left the registers
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    const int lin = tid + GT * k, col = lin / ON, e = lin % ON;
+                    const GV  r = *reinterpret_cast<const GV*>(img + img_at(col, e * LANES));
+                    gstore<NTS>(ot + (long long)(ph * CH * LANES + col) * omap.cstride + e, r);
+                    // four elements at a time: all E image reads in flight at once would need 4 E registers next to the 8 E of the
+                    // prefetched tile
+                    if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else
     for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
@@ -1569,12 +1679,12 @@ template <class V, class P, int CB, int DIR, bool NT, bool ROT = false, int WPC 
     return hipSuccess;
 }
 
-template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
+template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0, bool TOUT = false> hipError_t launch_dif2(const FftLaunch& L, hipStream_t stream) {
     using VT = VecTraits<V>;
     using W = typename VT::W;
     using GV = typename VT::G;
-    constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB>::LDS_BYTES;
-    auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT, ROT>;
+    constexpr size_t LDS_BYTES = Dif2Geom<V, PH, CB, TOUT>::LDS_BYTES;
+    auto kern = fft_dif2_tiles_kernel<V, PH, CB, DIR, NTL, NTS, BIN, BOUT, ROT, TOUT>;
     static std::atomic<int> blocks_per_cu[64];  // 0 = not set up on that device yet
     static std::mutex       setup_mutex;
     int         dev = 0;
@@ -1797,6 +1907,23 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                 (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
                 if (rot) return L.dir > 0 ? launch_dual<V, P, CBH, +1, true, true, 2>(L, stream) : launch_dual<V, P, CBH, -1, true, true, 2>(L, stream);
                 return L.dir > 0 ? launch_dual<V, P, CBH, +1, true, false, 2>(L, stream) : launch_dual<V, P, CBH, -1, true, false, 2>(L, stream);
+            }
+        }
+        if constexpr (!std::is_void<PH>::value && VecTraits<V>::LANES == 2 && P::N >= 2048) {  // (fp64: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
+            // forward X pass of lengths whose full-line tile does not fit the LDS (2048 points): DIF-split full-line tiles with the
+            // staged transposed store (round 6; fft_dif2_tiles_kernel, TOUT).  DFFT_X_DIF2=0: the paired half-line tiles of rounds 2-5.
+            static const bool x_dif2 = [] {
+                const char* e = getenv("DFFT_X_DIF2");
+                return !(e && *e == '0');
+            }();
+            constexpr int CBF = 128 / (int)sizeof(V);
+            const bool    transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1 && L.omap.last_delta == 0;
+            if (x_dif2 && L.dir > 0 && !general && transposed && L.imap.cstride == 1 && L.itile.b_stride == 1 && L.imap.nblk == 1 && L.imap.sub <= 1 && L.ncols % CBF == 0 &&
+                L.imap.last_delta == 0 && (axis_max_offset(L.imap, P::N / 2) + L.ncols) * (long long)sizeof(V) < (1ll << 32) && L.itile.b_stride == 1 &&
+                (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
+                // (the slab side of an X pass is a single-block map: offsets kk * step, no table)
+                if (rot) return launch_dif2<V, PH, CBF, +1, true, true, false, false, 2, true>(L, stream);
+                return launch_dif2<V, PH, CBF, +1, true, true, false, false, 0, true>(L, stream);
             }
         }
         if constexpr (can_dual) {
