@@ -28,6 +28,8 @@ struct Boot {
     int              rank = 0, size = 1;
     int              hub = -1;        // non-root: socket to rank 0
     std::vector<int> peers;           // root: socket per rank (index = rank; [0] unused)
+    bool             broken = false;  // a collective failed (time-out / dead peer): the byte streams may be mid-message, nothing more is read from them
+    uint32_t         magic = 0;       // hello word of THIS job (job_magic)
 } g;
 
 const char* env_first(std::initializer_list<const char*> names) {
@@ -100,7 +102,21 @@ const char* recv_why() {
            : g_recv_state == 2 ? "the peer closed the connection (it exited, or failed and left the rendezvous)"
                                : "socket error";
 }
-constexpr uint32_t HELLO_MAGIC = 0x44464654u;  // "DFFT": the listener behind the port really is this job's rank 0
+// Hello word: "DFFT" mixed with a hash of what every rank of ONE job agrees on (rendezvous address, port, world size; DFFT_JOB_ID if the
+// launcher sets one), so that a rank of another dfft job aimed at the same port is turned away like any other stranger.
+uint32_t job_magic(const char* addr, int port, int size) {
+    uint32_t h = 2166136261u;  // FNV-1a
+    auto mix = [&](const char* p) {
+        for (; p && *p; ++p) h = (h ^ (unsigned char)*p) * 16777619u;
+    };
+    mix(addr);
+    mix(":");
+    mix(std::to_string(port).c_str());
+    mix("/");
+    mix(std::to_string(size).c_str());
+    mix(getenv("DFFT_JOB_ID"));
+    return 0x44464654u ^ h;
+}
 unsigned long long g_ops = 0;                  // collective operations entered by this process (all ranks count alike)
 
 }  // namespace
@@ -125,6 +141,9 @@ int dfft_boot_init(void) {
     if (!addr) addr = "127.0.0.1";
     int portno = port ? atoi(port) : 29533;
     if (!getenv("DFFT_MASTER_PORT") && getenv("MASTER_PORT")) portno += 1;  // stay off torchrun's own store port
+
+    g.magic = job_magic(addr, portno, g.size);
+    g.broken = false;
 
     if (g.rank == 0) {
         int ls = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -192,20 +211,23 @@ int dfft_boot_init(void) {
             // hello = {magic, rank}; anything else (a port scanner, another job's client that guessed our port) is dropped
             // without failing the rendezvous
             uint32_t hello[2] = {0, 0};
-            if (!recv_all(fd, hello, sizeof(hello), 5000) || hello[0] != HELLO_MAGIC || hello[1] < 1 || (int)hello[1] >= g.size ||
-                g.peers[hello[1]] != -1) {
+            if (!recv_all(fd, hello, sizeof(hello), 5000) || hello[0] != g.magic || hello[1] < 1 || (int)hello[1] >= g.size) {
                 trace("boot: dropped a connection that is not a rank of this job", hello[0], hello[1]);
                 ::close(fd);
                 continue;
             }
-            const uint32_t ack[2] = {HELLO_MAGIC, (uint32_t)g.size};
+            const uint32_t ack[2] = {g.magic, (uint32_t)g.size};
             if (!send_all(fd, ack, sizeof(ack))) {
                 ::close(fd);
                 continue;
             }
+            // a second hello of a rank that is registered already: the client gave up on its first connection (its wait for the ack
+            // timed out while this loop was busy) and came back -- the NEW socket is the live one, the old one is closed on its side
+            const bool again = g.peers[hello[1]] != -1;
+            if (again) ::close(g.peers[hello[1]]);
             g.peers[hello[1]] = fd;
-            trace("boot: rank joined", hello[1], joined);
-            ++joined;
+            trace(again ? "boot: rank re-joined on a new connection" : "boot: rank joined", hello[1], joined);
+            if (!again) ++joined;
         }
         ::close(ls);
     } else {
@@ -220,16 +242,22 @@ int dfft_boot_init(void) {
         int one = 1;
         trace("boot: connecting to rank 0", portno, g.rank);
         int strangers = 0;
-        for (int attempt = 0; attempt < 600; ++attempt) {  // rank 0 may start later: retry for ~60 s
+        // rank 0 may start later: retry until DFFT_BOOT_TIMEOUT_S has elapsed in all (at least 60 s), whatever an attempt costs
+        const auto t_start = std::chrono::steady_clock::now();
+        const long long budget_ms = boot_timeout_ms() < 0 ? -1 : (boot_timeout_ms() < 60000 ? 60000 : boot_timeout_ms());
+        for (int attempt = 0;; ++attempt) {
+            if (attempt > 0 && budget_ms >= 0 &&
+                std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count() > budget_ms)
+                break;
             fd = ::socket(AF_INET, SOCK_STREAM, 0);
             if (fd >= 0 && ::connect(fd, res->ai_addr, res->ai_addrlen) == 0) {
                 // the listener must answer the hello with this job's magic and world size: a port that some OTHER listener
                 // happens to own (torchrun's store is one port below, RCCL's bootstrap sockets take ephemeral ports) accepts
                 // the connection too, and a rank that took it for rank 0 would wait in its first collective for ever
                 setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-                const uint32_t hello[2] = {HELLO_MAGIC, (uint32_t)g.rank};
+                const uint32_t hello[2] = {g.magic, (uint32_t)g.rank};
                 uint32_t       ack[2] = {0, 0};
-                if (send_all(fd, hello, sizeof(hello)) && recv_all(fd, ack, sizeof(ack), 10000) && ack[0] == HELLO_MAGIC &&
+                if (send_all(fd, hello, sizeof(hello)) && recv_all(fd, ack, sizeof(ack), 10000) && ack[0] == g.magic &&
                     (int)ack[1] == g.size)
                     break;
                 ++strangers;
@@ -254,12 +282,14 @@ int dfft_boot_rank(void) { return g.rank; }
 int dfft_boot_size(void) { return g.size; }
 
 static int boot_fail(const char* op, int peer) {
+    g.broken = true;  // the stream to that peer may have stopped mid-message: no later collective may read from it
     return fail(DFFT_ECOMM, std::string(op) + " (collective #" + std::to_string(g_ops) + " of rank " + std::to_string(g.rank) + "): waiting for rank " +
                                 std::to_string(peer) + ": " + recv_why());
 }
 
 int dfft_boot_bcast(void* buf, size_t bytes, int root) {
     if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
+    if (g.broken) return fail(DFFT_ECOMM, "dfft_boot_bcast: an earlier collective of this rendezvous failed (time-out or dead peer); it cannot be used again");
     if (g.size == 1 || bytes == 0) return DFFT_OK;
     ++g_ops;
     trace("boot: bcast enter", (long long)g_ops, root);
@@ -283,6 +313,7 @@ int dfft_boot_bcast(void* buf, size_t bytes, int root) {
 
 int dfft_boot_allreduce_max(double* v, int n) {
     if (!g.inited) return fail(DFFT_ECOMM, "dfft_boot: not initialised");
+    if (g.broken) return fail(DFFT_ECOMM, "dfft_boot_allreduce_max: an earlier collective of this rendezvous failed (time-out or dead peer); it cannot be used again");
     if (g.size == 1 || n <= 0) return DFFT_OK;
     const size_t bytes = sizeof(double) * (size_t)n;
     ++g_ops;

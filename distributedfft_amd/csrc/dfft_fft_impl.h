@@ -527,7 +527,14 @@ template <class V, class P, int CB, int G, class Tune> struct KernelGeom {
     // compiler goes 28-44 bytes over -- they keep that exchange in LDS (kernel_resources: 0 B either way in round 5's form)
     // (likewise the one-wavefront rows of 2048 fp64 points, 32 points = 128 registers of data per thread: 400 -> 440 registers and
     // 0.42 -> 0.455 ms per GiB with the exchange in registers, profiles/r06/experiments/long_axis_kernels_ab.txt)
-    static constexpr bool LOCALX = !(ROT2_PLAIN && P::E * (int)sizeof(V) / 4 >= 64) && !(CB == 1 && P::E * (int)sizeof(V) / 4 >= 128);
+    // (and 729 points -- 648-thread workgroups, 168 registers -- with per-point rotated offsets: 20-44 bytes over with three of the
+    // six radix-3 stages back to back; see also LOCALX_GENERAL in the kernel)
+#ifndef DFFT_729_LOCALX
+#define DFFT_729_LOCALX 0
+#endif
+    static constexpr bool LOCALX = !(ROT2_PLAIN && P::E * (int)sizeof(V) / 4 >= 64) && !(CB == 1 && P::E * (int)sizeof(V) / 4 >= 128) &&
+                                   (DFFT_729_LOCALX || !(ROT2_PLAIN && (P::N == 729 || (P::N == 768 && VecTraits<V>::LANES == 2 && Tune::ROT_IN == 2))));
+    // (768-point column pairs loading rotated points without a staged store -- an un-fused or natural-order forward X pass: 12 bytes over)
     static constexpr int EX_ELEMS = (P::S > 1) ? (PAD ? P::N + P::N / 8 : P::N) * CB / PH : 0;
     // staged image: one scalar column per row of N + OPAD twiddle-typed elements (OPAD = 2 keeps cpair rows 16-B aligned)
     static constexpr int LANES = VecTraits<V>::LANES;
@@ -824,7 +831,9 @@ fft_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* o
             load_tile(t0, v);
         }
 
-        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW, KG::PH, 1, KG::NW, KG::LOCALX>(v, twr, lds, j, c);
+        // (729-point column tiles with the ragged / uneven-slab address terms compiled in: 12 bytes over with the thread-local exchange)
+        constexpr bool LOCALX = KG::LOCALX && (DFFT_729_LOCALX || !(GENERAL && P::N == 729 && CB > 1));
+        run_stages<V, P, 0, DIR, CB, KG::PAD, KG::WAVE_LOCAL, KG::TWMODE, TWPOW, KG::PH, 1, KG::NW, LOCALX>(v, twr, lds, j, c);
 
         // normalisation folded into this pass: every result is multiplied on its way out (x * 1.0 is exact, so the default
         // changes nothing; a branch around a separate scaling loop cost 15 VGPRs and made the 16-point kernels spill)
@@ -1775,8 +1784,8 @@ template <class V, class P> constexpr int cols_per_tile() {
 
 // staging the transposed store pays when the tile rows are full 128-byte lines and the image fits the LDS
 // (N = 1024 fp64: 131 KiB, measured 3.4 -> 4.4 TB/s together with 16 points per thread; round 1)
-template <class V, class P> constexpr bool can_stage_store() {
-    constexpr int CBC = cols_per_tile<V, P>();
+template <class V, class P, int CBO = 0> constexpr bool can_stage_store() {
+    constexpr int CBC = CBO > 0 ? CBO : cols_per_tile<V, P>();
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;
     constexpr int L = VecTraits<V>::LANES;
     // (column pairs also stage with half-line tiles: their alternative is the scalar float2 kernel, 2048-point X pass)
@@ -1837,8 +1846,12 @@ template <class V, class P> hipError_t launch_rows(const FftLaunch& L, hipStream
 }
 
 // PH: plan of the half length (N / 2 points) for lengths whose non-transposing column passes run DIF-split (void: none)
-template <class V, class P, class PH = void> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
-    constexpr int CBC = cols_per_tile<V, P>();
+// CBO: columns per tile when not cols_per_tile() -- the half-line tiles of the "lean" lengths, see below.
+#ifndef DFFT_LEAN_COLS
+#define DFFT_LEAN_COLS 1
+#endif
+template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan(const FftLaunch& Lin, hipStream_t stream) {
+    constexpr int CBC = CBO > 0 ? CBO : cols_per_tile<V, P>();
     constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;  // column kernel
     if (!Lin.cols) return hipErrorInvalidValue;  // rows: launch_rows
     FftLaunch L = Lin;
@@ -1857,9 +1870,34 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
                         (L.rot.out_mode == 0 || (L.omap.cstride == 1 && L.otile.b_stride == 1));
         if (!ok) return hipErrorInvalidValue;
     }
-    if constexpr (CBC * P::T <= 1024) {
+    // "Lean" lengths (round 6): 1000, 1280 and 1536 points hold 10-24 points of 16 bytes per thread on full-line tiles of 512-800
+    // threads, and every variant that needs per-point offsets (packed / two-level maps, rotated rows, uneven slabs, the staged store)
+    // kept 52-320 bytes in scratch (profiles/r06/kernel_resources.txt of library b1622e22).  Full-line tiles stay where they are
+    // clean -- the Plain twins on single-block maps, the staged store of 1536 fp64 points -- and everything else runs on HALF-line
+    // tiles (4 columns: 256-400 threads, twice the register budget, no scratch; the XCD-aware tile order of fft_tiles_kernel gives
+    // the two tiles of a line to one L2).  -DDFFT_LEAN_COLS=0 restores the full-line variants (A/B builds).
+    constexpr bool lean_len = DFFT_LEAN_COLS && CBO == 0 && sizeof(V) == 16 && (P::N == 1000 || P::N == 1280 || P::N == 1536) && CBC >= 2;
+    if constexpr (lean_len) {
+        const bool single = L.imap.nblk == 1 && L.imap.sub <= 1 && L.omap.nblk == 1 && L.omap.sub <= 1;
+        const bool staged = can_stage_store<V, P>() && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
+        if (!general && !rot && single && !staged) {
+            if (L.dir > 0) {
+                if (L.hints & FFT_HINT_STREAM_OUT) return launch_variant<V, P, CBC, GC, +1, false, Plain<TuneColsStreamOut>>(L, stream);
+                return launch_variant<V, P, CBC, GC, +1, false, Plain<TuneCols>>(L, stream);
+            }
+            if (L.hints & FFT_HINT_STREAM_IN) return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneColsStreamIn>>(L, stream);
+            return launch_variant<V, P, CBC, GC, -1, false, Plain<TuneCols>>(L, stream);
+        }
+        if constexpr (P::N == 1536 && VecTraits<V>::LANES == 1 && can_stage_store<V, P>()) {
+            if (staged && !rot) {
+                if (L.dir > 0) return launch_variant<V, P, CBC, GC, +1, false, TuneTransposedStore>(L, stream);
+                return launch_variant<V, P, CBC, GC, -1, false, TuneTransposedStore>(L, stream);
+            }
+        }
+        return launch_plan<V, P, PH, CBC / 2>(Lin, stream);
+    } else if constexpr (CBC * P::T <= 1024) {
         // transposed INPUT side (the inverse X pass): staged load
-        if constexpr (can_tload<V, P>()) {
+        if constexpr (CBO == 0 && can_tload<V, P>()) {
             if (tload_applies<V, P>(L)) {
                 if (rot) return L.dir > 0 ? launch_tload<V, P, CBC, +1, true>(L, stream) : launch_tload<V, P, CBC, -1, true>(L, stream);
                 return L.dir > 0 ? launch_tload<V, P, CBC, +1, false>(L, stream) : launch_tload<V, P, CBC, -1, false>(L, stream);
@@ -1872,7 +1910,7 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
         // transposing store (unit stride along the FFT index on the output side, columns far apart): staged variant
         using TT = TuneTransposedStore;
         using TTF = TuneTransposedStoreFull;
-        constexpr bool can_stage = can_stage_store<V, P>();
+        constexpr bool can_stage = can_stage_store<V, P, CBO>();
         const bool staged = can_stage && !general && L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1;
         // 16 points of 16 bytes per thread on full-line tiles (the 1024-point forward X pass, fp64 and fp32 pairs): whole-tile prefetch
         // when the input side is a single-block map (TuneTransposedStoreFull); FFT_HINT_HALF_PREFETCH / FFT_HINT_EARLY_WAIT (the plan's
@@ -2013,7 +2051,7 @@ template <class V, class P, class PH = void> hipError_t launch_plan(const FftLau
             return hipErrorInvalidValue;
         }
         // single-block maps on both sides: the PLAIN twins of the column variants, for the lengths that need the registers
-        constexpr bool can_plain = P::N == 1000 || P::N == 1280 || P::N == 1536;
+        constexpr bool can_plain = CBO == 0 && (P::N == 1000 || P::N == 1280 || P::N == 1536);
         if constexpr (can_plain) {
             const bool single = L.imap.nblk == 1 && L.imap.sub <= 1 && L.omap.nblk == 1 && L.omap.sub <= 1;
             const bool is_staged = can_stage && staged;
@@ -2130,6 +2168,58 @@ template <class P> bool make_pair_launch(const FftLaunch& L, FftLaunch& out) {
         return true;
     }
     return false;
+}
+
+// Scalar float2 columns: the fall-back of fp32 column launches that make_pair_launch turns down (an odd Z length gives odd column
+// counts and strides; a caller's buffer that is only 8-byte aligned).  Up to round 5 they went through launch_plan like the other two
+// element types -- 16-19 variants per length on 16-column tiles, i.e. 1024-thread workgroups with a 128-register budget for every
+// length from 512 points on, and 150 of those kernels kept 12-204 bytes in scratch (profiles/r05/kernel_resources.txt).  Round 6
+// gives the fall-back a geometry of its own instead: at most 512 threads per workgroup (the 256-register budget), no register
+// prefetch, tid / CB butterfly ids, direct stores on a transposed side -- and eight kernels per length: whole-tile and ragged
+// (GENERAL) in both directions plus the four rotated-row twins a P > 1 plan can ask for.  No scratch in any of them
+// (profiles/r06/kernel_resources.txt); the stream hints are ignored (they select cache policies, not results).
+struct TuneScalar : TuneDefault {
+    static constexpr bool NO_OWNED = true;
+};
+template <class P> constexpr int cols_per_tile_scalar32() {
+    int cb = 128 / (int)sizeof(float2);
+    // (20 and more points per thread: 256 threads, i.e. one wave per SIMD and its 512 registers -- the unrolled exchanges of the five-
+    // and six-stage plans keep their LDS addresses in registers)
+    constexpr int MAXT = P::E >= 20 ? 256 : 512;
+    while (cb > 1 && (cb * P::T > MAXT || (long long)P::N * cb * (long long)sizeof(float2) > 128 * 1024)) cb /= 2;
+    return cb;
+}
+template <class P> hipError_t launch_scalar32(const FftLaunch& Lin, hipStream_t stream) {
+    using V = float2;
+    constexpr int CBC = cols_per_tile_scalar32<P>();
+    constexpr int GC = ConstMax1<256 / (CBC * P::T)>::value;
+    static_assert(CBC * P::T * GC <= 512, "the scalar fall-back keeps the 256-register budget");
+    if (!Lin.cols) return hipErrorInvalidValue;
+    FftLaunch L = Lin;
+    L.tiles_per_a = (L.ncols + CBC - 1) / CBC;
+    L.ntiles = L.na * L.tiles_per_a;
+    if (L.ntiles <= 0) return hipSuccess;
+    if (L.ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    const bool general = (L.ncols % CBC) != 0 || L.imap.last_delta != 0 || L.omap.last_delta != 0;
+    if (L.rot.in_mode != 0 || L.rot.out_mode != 0) {  // same admission rule as launch_plan (whole 128-byte lines move)
+        constexpr int LINE = 128 / (int)sizeof(V);
+        const bool ok = !general && L.rot.rot > 0 && L.rot.rot % LINE == 0 && (L.rot.mask + 1) % LINE == 0 && ((L.rot.mask + 1) & L.rot.mask) == 0 &&
+                        L.ncols == L.rot.mask + 1 && (L.rot.in_mode == 0 || (L.imap.cstride == 1 && L.itile.b_stride == 1)) &&
+                        (L.rot.out_mode == 0 || (L.omap.cstride == 1 && L.otile.b_stride == 1));
+        if (!ok) return hipErrorInvalidValue;
+        const int im = L.rot.in_mode, om = L.rot.out_mode;
+        if (L.dir > 0 && im == 0 && om == 1) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneScalar, 0, 1>>(L, stream);
+        if (L.dir > 0 && im == 2 && om == 0) return launch_variant<V, P, CBC, GC, +1, false, WithRot<TuneScalar, 2, 0>>(L, stream);
+        if (L.dir < 0 && im == 0 && om == 2) return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneScalar, 0, 2>>(L, stream);
+        if (L.dir < 0 && im == 1 && om == 0) return launch_variant<V, P, CBC, GC, -1, false, WithRot<TuneScalar, 1, 0>>(L, stream);
+        return hipErrorInvalidValue;
+    }
+    if (L.dir > 0) {
+        if (general) return launch_variant<V, P, CBC, GC, +1, true, TuneScalar>(L, stream);
+        return launch_variant<V, P, CBC, GC, +1, false, TuneScalar>(L, stream);
+    }
+    if (general) return launch_variant<V, P, CBC, GC, -1, true, TuneScalar>(L, stream);
+    return launch_variant<V, P, CBC, GC, -1, false, TuneScalar>(L, stream);
 }
 
 // One entry point per FFT length, explicitly instantiated in dfft_fft_inst.hip (split over translation units so the

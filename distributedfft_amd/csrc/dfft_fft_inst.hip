@@ -21,6 +21,13 @@ template <int N> struct PlanFor32 : PlanFor<N> {};
 // (512-point fp32 with 16 points per thread was also tried: X pass 0.567 -> 0.524 ms but the Z+Y stage 0.70 -> 1.00 ms.)
 template <> struct PlanFor32<1024> { using type = Plan<1024, 8, 8, 8, 8, 2>; };
 
+// Scalar float2 COLUMN fall-back (launch_scalar32: fp32 column launches that cannot run on column pairs): workgroups of at most 512
+// threads, so 1024 points run on the table's 16 points x 64 threads per column (8-column tiles, 64-byte pieces) instead of the fp32
+// plan's 8 x 128.  (2048 points on the row plan's 32 x 64 were tried for the same reason: 268-388 bytes of scratch; they keep 16 x 128
+// on 4-column tiles.)
+template <int N> struct PlanScalar32 : PlanFor32<N> {};
+template <> struct PlanScalar32<1024> : PlanFor<1024> {};
+
 // Row launches may use a plan of their own (launch_rows): 2048 contiguous points as one wave64 with 32 points per thread
 // (no s_barrier: 4.5 -> 5.3 TB/s fp64, 4.1 -> 5.1 fp32); the column kernel stays at 16 points per thread.
 template <int N> struct PlanRows : PlanFor<N> {};
@@ -52,7 +59,7 @@ template <int N> hipError_t launch_n(const FftLaunch& L, hipStream_t stream) {
         // column launches on even column counts run on column pairs with the fp64 geometry (16 bytes per lane)
         FftLaunch Lp;
         if (make_pair_launch<typename PlanFor<N>::type>(L, Lp)) return launch_plan<cpair, typename PlanFor<N>::type, typename PlanHalf<N>::type>(Lp, stream);
-        return launch_plan<float2, typename PlanFor32<N>::type>(L, stream);
+        return launch_scalar32<typename PlanScalar32<N>::type>(L, stream);
     }
     return hipErrorInvalidValue;
 }

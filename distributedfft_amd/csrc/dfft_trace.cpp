@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 
 namespace {
 struct Event {
+    std::atomic<unsigned> seq{0};  // index + 1 of the event this slot holds, published last (release); 0 while it is being rewritten
     double      t;     // seconds since the first event of the process
     const char* what;  // string literal
     long long   a, b;
@@ -40,35 +42,92 @@ int trace_rank() {
     return 0;
 }
 
+// The dump is written with write(2) from a stack buffer, formatted by hand: it also runs inside the SIGUSR2 handler, where stdio,
+// malloc and iostreams are off limits (a signal that arrives inside malloc or fprintf would dead-lock the rank it was sent to
+// diagnose).  clock_gettime, getpid, write and -- once libgcc is loaded, see install_handler -- backtrace / backtrace_symbols_fd are
+// async-signal-safe.
+struct Line {
+    char buf[320];
+    int  n = 0;
+    void str(const char* p) {
+        for (; p && *p && n < (int)sizeof(buf) - 1; ++p) buf[n++] = *p;
+    }
+    void num(long long v) {
+        char tmp[24];
+        int  k = 0;
+        unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+        do tmp[k++] = (char)('0' + u % 10); while ((u /= 10) != 0);
+        if (v < 0) tmp[k++] = '-';
+        while (k > 0 && n < (int)sizeof(buf) - 1) buf[n++] = tmp[--k];
+    }
+    void secs(double t) {  // seconds with four decimals
+        if (t < 0) t = 0;
+        const long long whole = (long long)t;
+        long long       frac = (long long)((t - (double)whole) * 10000.0);
+        num(whole);
+        str(".");
+        for (long long d = 1000; d >= 1; d /= 10) {
+            if (n < (int)sizeof(buf) - 1) buf[n++] = (char)('0' + frac / d);
+            frac %= d;
+        }
+    }
+    void flush() {
+        if (n < (int)sizeof(buf)) buf[n++] = '\n';
+        ssize_t r = ::write(2, buf, (size_t)n);
+        (void)r;
+        n = 0;
+    }
+};
+int g_rank = 0;  // read from the environment once, outside any handler (trace())
+
 void dump(const char* why, bool with_backtrace) {
     const unsigned n = g_next.load(std::memory_order_acquire);
     const unsigned first = n > RING ? n - RING : 0;
     const double   now = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count();
-    fprintf(stderr, "[dfft trace] rank %d pid %d: %s -- last %u of %u control-plane events (now = %.3f s)\n", trace_rank(), (int)getpid(), why, n - first,
-            n, now);
+    Line l;
+    l.str("[dfft trace] rank "); l.num(g_rank); l.str(" pid "); l.num((long long)getpid()); l.str(": "); l.str(why);
+    l.str(" -- last "); l.num(n - first); l.str(" of "); l.num(n); l.str(" control-plane events (now = "); l.secs(now); l.str(" s)");
+    l.flush();
     for (unsigned i = first; i < n; ++i) {
         const Event& e = g_ring[i % RING];
-        fprintf(stderr, "[dfft trace]   %10.4f s  %-34s %lld %lld\n", e.t, e.what ? e.what : "?", e.a, e.b);
+        // several threads write the ring: a slot is shown only if it holds event i completely (its sequence word is published last)
+        if (e.seq.load(std::memory_order_acquire) != i + 1) {
+            l.str("[dfft trace]   (event "); l.num(i); l.str(" is being overwritten)");
+            l.flush();
+            continue;
+        }
+        const double t = e.t;
+        const char*  w = e.what;
+        const long long a = e.a, b = e.b;
+        if (e.seq.load(std::memory_order_acquire) != i + 1) continue;  // overwritten while it was read
+        l.str("[dfft trace]   "); l.secs(t); l.str(" s  "); l.str(w ? w : "?"); l.str("  "); l.num(a); l.str(" "); l.num(b);
+        l.flush();
     }
     if (with_backtrace) {
         void*     frames[48];
         const int k = backtrace(frames, 48);
-        fprintf(stderr, "[dfft trace] native backtrace of the interrupted thread (%d frames):\n", k);
-        fflush(stderr);
+        l.str("[dfft trace] native backtrace of the interrupted thread ("); l.num(k); l.str(" frames):");
+        l.flush();
         backtrace_symbols_fd(frames, k, 2);
     }
-    fflush(stderr);
 }
 
-void on_sigusr2(int) { dump("SIGUSR2", true); }
+void on_sigusr2(int) {
+    const int saved = errno;
+    dump("SIGUSR2", true);
+    errno = saved;
+}
 }  // namespace
 
 namespace dfft {
 
 void trace(const char* what, long long a, long long b) {
     if (!g_signal_checked.exchange(true)) {
+        g_rank = trace_rank();
         const char* e = getenv("DFFT_TRACE_SIGNAL");
         if (e && *e && *e != '0') {
+            void* warm[4];
+            (void)backtrace(warm, 4);  // the first call loads libgcc_s (dlopen, malloc): do it here, not inside the handler
             struct sigaction sa;
             std::memset(&sa, 0, sizeof(sa));
             sa.sa_handler = on_sigusr2;
@@ -77,10 +136,12 @@ void trace(const char* what, long long a, long long b) {
     }
     const unsigned i = g_next.fetch_add(1, std::memory_order_acq_rel);
     Event&         e = g_ring[i % RING];
+    e.seq.store(0, std::memory_order_release);
     e.t = std::chrono::duration<double>(std::chrono::steady_clock::now() - g_t0).count();
     e.what = what;
     e.a = a;
     e.b = b;
+    e.seq.store(i + 1, std::memory_order_release);
 }
 
 void trace_on_error(int code, const std::string& msg) {
@@ -91,6 +152,18 @@ void trace_on_error(int code, const std::string& msg) {
     }();
     if (!on) return;
     trace("error", code, 0);
+    // one ring per burst of failures: cascaded errors (every plan of a communicator whose peer died) and tests that provoke
+    // DFFT_ECOMM on purpose would otherwise print up to 256 lines each.  Later failures within 5 s get one line.
+    static std::atomic<long long> last_ms{-1000000};
+    const long long now_ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - g_t0).count();
+    const long long prev = last_ms.load();
+    if (now_ms - prev >= 5000) last_ms.store(now_ms);
+    if (now_ms - prev < 5000) {
+        Line l;
+        l.str("[dfft trace] rank "); l.num(g_rank); l.str(": "); l.str(msg.c_str()); l.str(" (event ring printed "); l.num(now_ms - prev); l.str(" ms ago, not repeated)");
+        l.flush();
+        return;
+    }
     dump(msg.c_str(), false);
 }
 

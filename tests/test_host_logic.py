@@ -352,6 +352,40 @@ def test_headline_kernels_do_not_spill():
         assert vgpr <= (224 if "lazy" in tag and " Y=768 " not in tag else 256), f"{tag}: {vgpr} registers"
 
 
+def test_kernel_inventory_is_current_and_nothing_up_to_2048_points_spills():
+    """profiles/r06/kernel_resources.txt (tools/kernel_resources.py all: every instantiation group + the one-launch YZ stage,
+    cross-compiled for gfx950) must belong to the kernel sources in the tree -- its first line carries their sha256 -- and must show no
+    scratch for any kernel of a length up to 2048 points, i.e. for every kernel a 3D plan on such lengths can select: fp64, fp32 column
+    pairs AND the scalar float2 fall-back an odd fp32 Z length runs on.  Compiling all twelve groups takes half an
+    hour on this container, so the inventory is committed and this test pins it to the sources; the spill-prone groups of the BASELINE
+    lengths are still compiled live by test_headline_kernels_do_not_spill."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("kernel_resources", ROOT / "tools" / "kernel_resources.py")
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    lines = (ROOT / "profiles" / "r06" / "kernel_resources.txt").read_text().splitlines()
+    m = re.match(r"# kernel sources sha256 ([0-9a-f]{64})", lines[0])
+    assert m, lines[0]
+    assert m.group(1) == kr.sources_sha256(), "kernel sources changed: run  python tools/kernel_resources.py all profiles/r06/kernel_resources.txt"
+    rows = [ln for ln in lines[1:] if ln.strip()]
+    assert 1500 < len(rows) < 2700, len(rows)
+    seen_scalar = 0
+    for ln in rows:
+        scratch = int(re.search(r"scratch\s+(\d+) B", ln).group(1))
+        n = re.search(r" N=(\d+) ", ln)
+        if n and int(n.group(1)) > 2048:
+            continue  # 2187 ... 4096 points: single-pass lengths beyond every BASELINE axis (DESIGN section 8)
+        allowed = 0
+        if ln.startswith("pair") and "DualTiles" in ln:
+            allowed = 16   # one 64-bit address per tile pair, outside the point loops (see test_headline_kernels_do_not_spill)
+        if "zy_chunk_kernel" in ln and " Y=768 " in ln and "packed=1 eager" in ln:
+            allowed = 96   # the eager-publish twins are the tests' bit-identity reference, not a shipped path
+        assert scratch <= allowed, ln
+        seen_scalar += ln.startswith("f32") and "TuneScalar" in ln
+    assert seen_scalar >= 8 * 40, seen_scalar  # the float2 fall-back: eight kernels per length
+
+
 def test_bench_recognises_the_forward_yz_stage_in_rocprof_names():
     """bench.py's in-run counter pass finds t0's launches by kernel name (roofline.traffic of the dominant kernel).  The names carry the
     kernel's template arguments; when the stage gained a parameter in round 5 the pattern missed them all and the traffic came out null."""

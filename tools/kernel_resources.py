@@ -3,6 +3,9 @@ csrc/dfft_fft_inst.hip for gfx950 with -save-temps and reads the .amdhsa_* direc
 
   python tools/kernel_resources.py <group> [filter]        e.g.  python tools/kernel_resources.py 3 N=512
   python tools/kernel_resources.py zy                      the kernels of the one-launch YZ stage (csrc/dfft_zy.hip)
+  python tools/kernel_resources.py all <out.txt> [jobs]    every group + zy into one inventory whose first line carries the sha256 of the
+                                                           kernel sources (tests/test_host_logic.py checks that the committed inventory
+                                                           belongs to the sources in the tree and that nothing up to 2048 points spills)
 
 A kernel that spills (scratch > 0) or loses occupancy shows up here long before it shows up in a benchmark: the 16- and
 24-point-per-thread column kernels sit within a few registers of the 256-VGPR budget of a 512-thread block."""
@@ -97,7 +100,40 @@ def zy_table():
     return rows
 
 
+KERNEL_SOURCES = ("dfft_fft_impl.h", "dfft_butterfly.h", "dfft_plans.h", "dfft_fft_inst.hip", "dfft_zy.hip", "dfft_zy.h", "dfft_kernels.h")
+
+
+def sources_sha256() -> str:
+    """sha256 over the files every FFT kernel instantiation is generated from."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update((CSRC / name).read_bytes())
+    return h.hexdigest()
+
+
+def num_groups() -> int:
+    return int(re.search(r"#define DFFT_NUM_INST_GROUPS (\d+)", (CSRC / "dfft_plans.h").read_text()).group(1))
+
+
+def write_inventory(out: Path, jobs: int = 4):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        tables = list(ex.map(kernel_table, range(num_groups()))) + [zy_table()]
+    lines = [f"# kernel sources sha256 {sources_sha256()}  ({' '.join(KERNEL_SOURCES)}; tools/kernel_resources.py all)"]
+    for rows in tables:
+        for tag, vgpr, scratch, lds in rows:
+            lines.append(f"{tag:<70} vgpr {vgpr:>3}  scratch {scratch:>4} B")
+    out.write_text("\n".join(lines) + "\n")
+    return len(lines) - 1
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "all":
+        n = write_inventory(Path(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 4)
+        print(f"{n} kernels -> {sys.argv[2]}")
+        sys.exit(0)
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     rows = zy_table() if len(sys.argv) > 1 and sys.argv[1] == "zy" else kernel_table(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
     for tag, vgpr, scratch, lds in rows:
