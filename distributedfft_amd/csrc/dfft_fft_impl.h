@@ -1790,7 +1790,8 @@ template <class V, class P, int CBO = 0> constexpr bool can_stage_store() {
     constexpr int L = VecTraits<V>::LANES;
     // (column pairs also stage with half-line tiles: their alternative is the scalar float2 kernel, 2048-point X pass)
     constexpr int PH = (size_t)P::N * CBC * sizeof(V) > 128 * 1024 ? 2 : 1;  // KernelGeom::PH
-    return P::S > 1 && CBC * (int)sizeof(V) >= (L == 2 ? 64 : 128) && P::N % L == 0 &&
+    // (... and so do the half-line tiles of the lean lengths, CBO > 0: what the image buys is 1 KiB runs on the OUTPUT side)
+    return P::S > 1 && CBC * (int)sizeof(V) >= ((L == 2 || CBO > 0) ? 64 : 128) && P::N % L == 0 &&
            (size_t)(P::N + (L == 2 ? 2 : 1)) * CBC / PH * GC * sizeof(V) <= 144 * 1024;
 }
 

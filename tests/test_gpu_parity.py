@@ -187,6 +187,15 @@ SHAPES = [
     ((16, 24, 1536), 2), ((60, 64, 20), 8),
     # the top of the single-pass range on every axis: 4096 (16 points per thread, 2-column tiles) and 2401 = 7^4
     ((4, 4096, 8), 2), ((2, 8, 4096), 1), ((2401, 3, 4), 1), ((4, 6, 2401), 2),
+    # round 6, the "lean" lengths (1000 / 1280 / 1536 points: half-line tiles wherever a variant needs per-point offsets): X pass staged
+    # on half-line tiles (fp64 and pairs), Y pass into the packed layout, uneven Y splits (ragged address terms), P = 1 plain twins
+    ((1536, 8, 16), 1), ((1536, 8, 16), 2), ((1280, 8, 16), 4), ((1280, 4, 16), 1), ((1000, 8, 16), 1), ((1000, 8, 16), 2),
+    ((8, 1536, 16), 2), ((4, 1536, 16), 1), ((8, 1280, 16), 4), ((8, 1000, 16), 2), ((12, 1000, 8), 3), ((12, 1280, 8), 3), ((12, 1536, 12), 4),
+    ((729, 9, 8), 3), ((8, 729, 8), 2),
+    # round 6, an ODD Z length: fp32 column launches cannot run on column pairs and take the scalar float2 fall-back (launch_scalar32,
+    # eight kernels per length on a geometry of its own) -- short and long X / Y axes, packed and ragged
+    ((512, 8, 9), 1), ((8, 1024, 7), 2), ((2048, 2, 5), 1), ((4, 768, 5), 2), ((640, 4, 3), 2), ((16, 2048, 3), 2), ((1536, 4, 3), 1),
+    ((12, 400, 5), 3), ((343, 4, 7), 1),
 ]
 
 
@@ -753,7 +762,10 @@ def test_overlap_mode_part_exchange_vs_oracle(gpu, N, P, parts, yparts, monkeypa
 # reach every kernel with a rotated side: 512-point tiles (staged X pass), 16 points per thread (1024), radix-3 Y axis (768),
 # the 2048-point DIF-split Y pass and paired-tile X pass, half-line fallbacks, fp32 column pairs and scalar fp32 columns
 ROT_SHAPES = [((64, 64, 64), 2), ((64, 64, 64), 4), ((128, 128, 32), 8), ((512, 8, 32), 2), ((1024, 8, 64), 4), ((16, 768, 16), 2),
-              ((2048, 8, 16), 2), ((2048, 8, 8), 4), ((8, 2048, 16), 2), ((16, 2048, 32), 4), ((32, 32, 16), 2), ((24, 40, 256), 4)]
+              ((2048, 8, 16), 2), ((2048, 8, 8), 4), ((8, 2048, 16), 2), ((16, 2048, 32), 4), ((32, 32, 16), 2), ((24, 40, 256), 4),
+              # round 6: rotated sides on the half-line tiles of the lean lengths (staged X pass, Y pass storing rotated tiles), 729 points
+              ((1536, 8, 16), 2), ((1280, 8, 32), 4), ((1000, 8, 16), 2), ((8, 1536, 16), 2), ((16, 1280, 16), 4), ((8, 1000, 32), 2),
+              ((729, 9, 16), 3), ((8, 729, 16), 2)]
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
