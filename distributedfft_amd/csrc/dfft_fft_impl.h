@@ -1877,6 +1877,16 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
     // clean -- the Plain twins on single-block maps, the staged store of 1536 fp64 points -- and everything else runs on HALF-line
     // tiles (4 columns: 256-400 threads, twice the register budget, no scratch; the XCD-aware tile order of fft_tiles_kernel gives
     // the two tiles of a line to one L2).  -DDFFT_LEAN_COLS=0 restores the full-line variants (A/B builds).
+    // -DDFFT_LEAN_EXTRA=1 (experiment, round 6): the same half-line tiles for the packed / rotated variants of 768 and 1024 points, which
+    // do NOT spill -- does a 256-thread workgroup with two or three of its kind resident per CU beat the 512-thread full-line tile?
+#ifndef DFFT_LEAN_EXTRA
+#define DFFT_LEAN_EXTRA 0
+#endif
+    constexpr bool lean_extra = DFFT_LEAN_EXTRA && CBO == 0 && sizeof(V) == 16 && (P::N == 768 || P::N == 1024) && CBC >= 2;
+    if constexpr (lean_extra) {
+        const bool single = L.imap.nblk == 1 && L.imap.sub <= 1 && L.omap.nblk == 1 && L.omap.sub <= 1;
+        if (!general && (rot || !single)) return launch_plan<V, P, void, CBC / 2>(Lin, stream);
+    }
     constexpr bool lean_len = DFFT_LEAN_COLS && CBO == 0 && sizeof(V) == 16 && (P::N == 1000 || P::N == 1280 || P::N == 1536) && CBC >= 2;
     if constexpr (lean_len) {
         const bool single = L.imap.nblk == 1 && L.imap.sub <= 1 && L.omap.nblk == 1 && L.omap.sub <= 1;
