@@ -1879,6 +1879,9 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
     // the two tiles of a line to one L2).  -DDFFT_LEAN_COLS=0 restores the full-line variants (A/B builds).
     // -DDFFT_LEAN_EXTRA=1 (experiment, round 6): the same half-line tiles for the packed / rotated variants of 768 and 1024 points, which
     // do NOT spill -- does a 256-thread workgroup with two or three of its kind resident per CU beat the 512-thread full-line tile?
+    // Measured and NOT adopted (profiles/r06/experiments/lib_ab_lean_extra_768_1024.log, bit-identical): config 4's rank at P = 8
+    // t0 0.56 -> 0.60 ms, t3 0.35 -> 0.46; 1024^3 fp32 at P = 4 1.45 / 0.82 -> 1.58 / 1.16.  What the lean lengths gain is the scratch
+    // they lose, not the geometry.
 #ifndef DFFT_LEAN_EXTRA
 #define DFFT_LEAN_EXTRA 0
 #endif
