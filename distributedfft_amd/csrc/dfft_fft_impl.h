@@ -1159,7 +1159,12 @@ template <class V, class PH, int CB, bool TOUT = false> struct Dif2Geom {
     static constexpr size_t TW_BYTES = ((size_t)2 * PH::N * sizeof(W) + 15) / 16 * 16;  // the whole N-point table
     static constexpr size_t TILE_BYTES = (size_t)PH::N * CB * sizeof(V);
     // image of CB / 2 columns: padded rows where they fit next to the table, else rows of N rotated by their index (fft_dual_tiles_kernel)
-    static constexpr bool   PADROW = TW_BYTES + (size_t)(CB / 2) * LANES * (N + OPAD) * sizeof(W) <= 160 * 1024;
+    // (... and where rows of exactly N let TWO workgroups share the CU -- 1024 fp64 points: 16 + 64 KiB -- the pad is not worth the second
+    // workgroup it would cost)
+    static constexpr size_t IMG_PLAIN = (size_t)(CB / 2) * LANES * N * sizeof(W);
+    static constexpr bool   TWO_PER_CU = TOUT && TW_BYTES + (TILE_BYTES > IMG_PLAIN ? TILE_BYTES : IMG_PLAIN) <= 80 * 1024;
+    static constexpr size_t BUDGET = TWO_PER_CU ? 80 * 1024 : 160 * 1024;
+    static constexpr bool   PADROW = TW_BYTES + (size_t)(CB / 2) * LANES * (N + OPAD) * sizeof(W) <= BUDGET;
     static constexpr int    ROW = PADROW ? N + OPAD : N;
     static constexpr size_t IMG_BYTES = TOUT ? (size_t)(CB / 2) * LANES * ROW * sizeof(W) : 0;
     static constexpr size_t LDS_BYTES = TW_BYTES + (TILE_BYTES > IMG_BYTES ? TILE_BYTES : IMG_BYTES);
@@ -1168,7 +1173,7 @@ template <class V, class PH, int CB, bool TOUT = false> struct Dif2Geom {
 // BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
 // which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
 template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0, bool TOUT = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(1)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(Dif2Geom<V, PH, CB, TOUT>::TWO_PER_CU ? (CB * PH::T) / 128 : 1)))
 fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
                       double scale, RotMap rm) {
@@ -1961,7 +1966,17 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
                 return L.dir > 0 ? launch_dual<V, P, CBH, +1, true, false, 2>(L, stream) : launch_dual<V, P, CBH, -1, true, false, 2>(L, stream);
             }
         }
-        if constexpr (!std::is_void<PH>::value && VecTraits<V>::LANES == 2 && P::N >= 2048) {  // (fp64: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
+        // The same kernel for the 1024-point forward X pass (round 6, config 4's t3): two 512-point half transforms through a 64 KiB tile
+        // + 16 KiB table = 80 KiB, so TWO workgroups share a CU and one transforms while the other's loads and stores are in flight (at most
+        // 128 registers each: Dif2Geom::TWO_PER_CU) -- instead of TuneTransposedStoreFull's one 128 KiB tile with a whole-tile prefetch.
+        // Measured (profiles/r06/experiments/lib_ab_x_pass_1024_dif2.log, three processes each, DFFT_X_DIF2=0 against the default): fp64
+        // config 4's rank at P = 8 0.342 -> 0.306 ms, at P = 4 0.682 -> 0.582, one GPU 2.56 -> 2.32, 1024 x 1024 x 512 at P = 8 0.453 -> 0.393;
+        // fp32 pairs with rotated rows (P > 1) 0.175 -> 0.162 and 0.828 -> 0.795, but on the padded hand-over buffer of a single-GPU plan
+        // 1.08 -> 1.19 and 2.81 -> 3.13 -- so pairs take it only with rotated rows.  -DDFFT_X_DIF2_1024=0 compiles it out.
+#ifndef DFFT_X_DIF2_1024
+#define DFFT_X_DIF2_1024 1
+#endif
+        if constexpr (!std::is_void<PH>::value && ((VecTraits<V>::LANES == 2 && P::N >= 2048) || (DFFT_X_DIF2_1024 && P::N == 1024))) {  // (fp64 2048: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
             // forward X pass of lengths whose full-line tile does not fit the LDS (2048 points): DIF-split full-line tiles with the
             // staged transposed store (round 6; fft_dif2_tiles_kernel, TOUT).  DFFT_X_DIF2=0: the paired half-line tiles of rounds 2-5.
             static const bool x_dif2 = [] {
@@ -1970,7 +1985,8 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
             }();
             constexpr int CBF = 128 / (int)sizeof(V);
             const bool    transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1 && L.omap.last_delta == 0;
-            if (x_dif2 && L.dir > 0 && !general && transposed && L.imap.cstride == 1 && L.itile.b_stride == 1 && L.imap.nblk == 1 && L.imap.sub <= 1 && L.ncols % CBF == 0 &&
+            const bool want = P::N >= 2048 || VecTraits<V>::LANES == 1 || rot;
+            if (x_dif2 && want && L.dir > 0 && !general && transposed && L.imap.cstride == 1 && L.itile.b_stride == 1 && L.imap.nblk == 1 && L.imap.sub <= 1 && L.ncols % CBF == 0 &&
                 L.imap.last_delta == 0 && (axis_max_offset(L.imap, P::N / 2) + L.ncols) * (long long)sizeof(V) < (1ll << 32) && L.itile.b_stride == 1 &&
                 (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
                 // (the slab side of an X pass is a single-block map: offsets kk * step, no table)
