@@ -1972,11 +1972,13 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
         // Measured (profiles/r06/experiments/lib_ab_x_pass_1024_dif2.log, three processes each, DFFT_X_DIF2=0 against the default): fp64
         // config 4's rank at P = 8 0.342 -> 0.306 ms, at P = 4 0.682 -> 0.582, one GPU 2.56 -> 2.32, 1024 x 1024 x 512 at P = 8 0.453 -> 0.393;
         // fp32 pairs with rotated rows (P > 1) 0.175 -> 0.162 and 0.828 -> 0.795, but on the padded hand-over buffer of a single-GPU plan
-        // 1.08 -> 1.19 and 2.81 -> 3.13 -- so pairs take it only with rotated rows.  -DDFFT_X_DIF2_1024=0 compiles it out.
+        // 1.08 -> 1.19 and 2.81 -> 3.13 -- and a rule "pairs only with rotated rows" would give up the bit-identity of rotated and
+        // un-rotated pipelines (test_rotated_exchange_rows_vs_oracle), so 1024-point pairs stay on TuneTransposedStoreFull.
+        // -DDFFT_X_DIF2_1024=0 compiles it out.
 #ifndef DFFT_X_DIF2_1024
 #define DFFT_X_DIF2_1024 1
 #endif
-        if constexpr (!std::is_void<PH>::value && ((VecTraits<V>::LANES == 2 && P::N >= 2048) || (DFFT_X_DIF2_1024 && P::N == 1024))) {  // (fp64 2048: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
+        if constexpr (!std::is_void<PH>::value && ((VecTraits<V>::LANES == 2 && P::N >= 2048) || (DFFT_X_DIF2_1024 && P::N == 1024 && VecTraits<V>::LANES == 1))) {  // (fp64 2048: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
             // forward X pass of lengths whose full-line tile does not fit the LDS (2048 points): DIF-split full-line tiles with the
             // staged transposed store (round 6; fft_dif2_tiles_kernel, TOUT).  DFFT_X_DIF2=0: the paired half-line tiles of rounds 2-5.
             static const bool x_dif2 = [] {
@@ -1985,7 +1987,7 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
             }();
             constexpr int CBF = 128 / (int)sizeof(V);
             const bool    transposed = L.omap.nblk == 1 && L.omap.stride == 1 && L.omap.cstride != 1 && L.omap.last_delta == 0;
-            const bool want = P::N >= 2048 || VecTraits<V>::LANES == 1 || rot;
+            constexpr bool want = P::N >= 2048 || VecTraits<V>::LANES == 1;
             if (x_dif2 && want && L.dir > 0 && !general && transposed && L.imap.cstride == 1 && L.itile.b_stride == 1 && L.imap.nblk == 1 && L.imap.sub <= 1 && L.ncols % CBF == 0 &&
                 L.imap.last_delta == 0 && (axis_max_offset(L.imap, P::N / 2) + L.ncols) * (long long)sizeof(V) < (1ll << 32) && L.itile.b_stride == 1 &&
                 (!rot || (L.rot.in_mode == 2 && L.rot.out_mode == 0))) {
