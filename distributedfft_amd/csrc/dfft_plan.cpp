@@ -1427,7 +1427,11 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         //    (96-row blocks, two offset tables per thread half) 0.57-0.60 / 0.91-0.93 -> 0.62 / 0.94 whatever the phase size
         //    (profiles/r05/experiments/variant_ab_768_final.log, c4_p8_one_launch_sweep.log): used by itself where a destination block is
         //    whole 64-row strides of the column unit, i.e. up to P = 4 for this axis.
-        const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512 && ysub % 64 == 0) || (oe && !strcmp(oe, "all"));
+        //  * round 6, overlapped forward plans: the ONE launch for all parts (zy_part_done below) also pays on 96-row destination blocks --
+        //    config 4 per rank at P = 4 (two Y sub-blocks of 96 rows), overlapped t0 1.16 -> 1.05 ms against 1.03 for the serial plan
+        //    (profiles/r06/experiments/c4_overlap_one_launch.log): what it replaces there is one launch pair PER PART, not per cache chunk.
+        const bool      parts_fwd = p->part_planes > 0 && direction == DFFT_FORWARD && p->zy_lazy;
+        const bool      multi_on = (n1 == 512 && n2 == 512) || (n1 == 768 && n2 == 512 && (ysub % 64 == 0 || parts_fwd)) || (oe && !strcmp(oe, "all"));
         if (!(oe && *oe == '0') && (single_ok || (multi_ok && multi_on)) && !(flags & (DFFT_PLAN_UNFUSED | DFFT_PLAN_NATURAL)) && !p->long_axis &&
             zy_supported(dtype, (int)n1, (int)n2) && p->xs <= ZY_MAX_PLANES) {
             p->zy_eligible = true;
@@ -1500,6 +1504,14 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                 if (q > 1 && fit >= 2 * q) fit -= fit % q;
             }
             p->chunk_planes = fit;
+            // Overlapped plans on two launches per PART (no one-launch stage for the shape): a part is one Z + Y launch pair, so the same
+            // rule sizes it -- when that does not change the number of parts (the overlap's granularity): config 4 per rank at P = 8,
+            // 4 x 32 -> 3 x 40 + 8 planes (a 32-plane launch pair runs at the rate of a 32-plane chunk: serial t0 0.547 ms with 40-plane
+            // chunks, 0.59 with 32, 0.616 for the four 32-plane parts; profiles/r06/experiments/c4_overlap_one_launch.log).  Decided from
+            // rank-symmetric data only (the shape predicate zy_eligible, the global block size): every rank cuts the same parts.
+            const long long blk = p->sx.blk, pp = p->part_planes;
+            if (pp > 0 && !p->zy_eligible && !getenv("DFFT_OVERLAP_PARTS") && !ce && fit > pp && fit < blk && (blk + fit - 1) / fit == (blk + pp - 1) / pp)
+                p->part_planes = fit;
         } else if (mb > 0) {
             const long long plane_b = n1 * n2 * (long long)elem_bytes(dtype);
             long long       fit = std::max(1ll, (mb << 20) / plane_b);

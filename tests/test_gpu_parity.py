@@ -538,7 +538,8 @@ def test_one_launch_t0_failure_is_collective(gpu, monkeypatch):
 
 @pytest.mark.parametrize("rot", ["0", "1"])
 @pytest.mark.parametrize("N,P", [((8, 256, 256), 2), ((16, 256, 512), 4), ((16, 512, 256), 2), ((32, 256, 256), 8), ((24, 512, 512), 4),
-                                 ((16, 768, 512), 8), ((8, 768, 512), 2)])   # config 4's planes: blocks of 96 / 384 rows per destination
+                                 ((16, 768, 512), 8), ((8, 768, 512), 2),    # config 4's planes: blocks of 96 / 384 rows per destination
+                                 ((16, 768, 512), 4)])   # ... and 192 rows: two Y sub-blocks of 96 in the overlapped plan (one launch for all parts)
 def test_one_launch_t0_with_exchange_is_bit_identical(gpu, N, P, rot, monkeypatch):
     """P > 1: the one-launch YZ stage stores its column results straight into the packed (and, with DFFT_ROT=1, row-rotated) send
     layout, the inverse reads the packed receive layout -- whole slabs in the serial pipeline, X-plane parts in the overlapped

@@ -4,7 +4,7 @@ garbage), so t0 (Z + Y passes, Y storing the packed send layout) and t3 (X pass 
 with the real P > 1 address maps.  Every configuration is measured with the rows of the exchange buffers rotated (DFFT_ROT=1)
 and not (DFFT_ROT=0), alternating, on `reps` freshly created plans each (a plan's buffers land in different physical regions
 from one creation to the next, which is worth 5-8 % of the X pass: profiles/r03/README.md section 1).
-usage: local_by_P.py [n0xn1xn2] [fp64|fp32] [reps]"""
+usage: local_by_P.py [n0xn1xn2] [fp64|fp32] [reps] [P,P,...] [serial|overlap]"""
 import os
 import sys
 from pathlib import Path
@@ -24,7 +24,8 @@ S = 16 if prec == "fp64" else 8
 dev = torch.device("cuda:0")
 n0, n1, n2 = size
 print(f"# local work per rank, {n0}x{n1}x{n2} {prec}: P, pipeline, rot, t0 ms, t3 ms (median over {reps} plans; min..max), X pass GB/s = 2 S N/P / t3")
-for P in (1, 2, 4, 8):
+PS = tuple(int(v) for v in sys.argv[4].split(",")) if len(sys.argv) > 4 else (1, 2, 4, 8)
+for P in PS:
     if n0 % P or n1 % P:
         continue
     mc = api.get_max_data_count(n0, n1, n2, P, False)
@@ -35,7 +36,7 @@ for P in (1, 2, 4, 8):
     b = torch.zeros_like(a)
     comm = api.Comm.local(P) if P > 1 else None
     for flags, name in ((api.PLAN_INPUT_FROM_IN, "serial"), (api.PLAN_INPUT_FROM_IN | api.PLAN_OVERLAP, "overlap")):
-        if P == 1 and name == "overlap":
+        if (P == 1 and name == "overlap") or (len(sys.argv) > 5 and sys.argv[5] != name):
             continue
         res = {0: [], 1: []}
         for r in range(reps):
