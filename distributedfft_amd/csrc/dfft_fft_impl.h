@@ -1164,6 +1164,8 @@ template <class V, class PH, int CB, bool TOUT = false> struct Dif2Geom {
     static constexpr size_t IMG_PLAIN = (size_t)(CB / 2) * LANES * N * sizeof(W);
     static constexpr bool   TWO_PER_CU = TOUT && TW_BYTES + (TILE_BYTES > IMG_PLAIN ? TILE_BYTES : IMG_PLAIN) <= 80 * 1024;
     static constexpr size_t BUDGET = TWO_PER_CU ? 80 * 1024 : 160 * 1024;
+    // (-DDFFT_DIF2_HALF experiment) half-line tiles of the non-transposing passes: two workgroups per CU where half tile + table allow it
+    static constexpr bool   HALF2 = !TOUT && (size_t)CB * sizeof(V) < 128 && TW_BYTES + TILE_BYTES <= 80 * 1024;
     static constexpr bool   PADROW = TW_BYTES + (size_t)(CB / 2) * LANES * (N + OPAD) * sizeof(W) <= BUDGET;
     static constexpr int    ROW = PADROW ? N + OPAD : N;
     static constexpr size_t IMG_BYTES = TOUT ? (size_t)(CB / 2) * LANES * ROW * sizeof(W) : 0;
@@ -1173,7 +1175,7 @@ template <class V, class PH, int CB, bool TOUT = false> struct Dif2Geom {
 // BIN / BOUT: the side's wave-uniform offsets come from a table computed once (any map); false = k * step for single-block maps,
 // which measured 150 B of scratch against none with the tables, so the launcher always asks for both.
 template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool BOUT, int ROT = 0, bool TOUT = false>
-__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu(Dif2Geom<V, PH, CB, TOUT>::TWO_PER_CU ? (CB * PH::T) / 128 : 1)))
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PH::T), amdgpu_waves_per_eu((Dif2Geom<V, PH, CB, TOUT>::TWO_PER_CU || Dif2Geom<V, PH, CB, TOUT>::HALF2) ? (CB * PH::T) / 128 : 1)))
 fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
                       AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
                       double scale, RotMap rm) {
@@ -1433,8 +1435,19 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
                 }
             }
         }
-    } else
-    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    } else {
+    // half-line tiles (CB columns narrower than a cache line; -DDFFT_DIF2_HALF experiment): the XCD-aware tile order of fft_tiles_kernel --
+    // the Q tiles that share the lines of a row segment go to workgroups on the same XCD
+    constexpr int  Q = (CB * sizeof(V) < 128) ? (int)(128 / (CB * sizeof(V))) : 1;
+    const unsigned remap_full = (Q > 1 && tiles_per_a % Q == 0) ? (ntiles / (8u * Q)) * (8u * Q) : 0u;
+    for (unsigned tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        unsigned t = tl;
+        if constexpr (Q > 1) {
+            if (tl < remap_full) {
+                const unsigned xcd = tl & 7u, s = tl >> 3;
+                t = ((s / Q) * 8u + xcd) * Q + (s % Q);
+            }
+        }
         const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
         // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row by the plane's rotation
         int cbi = (int)(b * CB), cbo = (int)(b * CB);
@@ -1465,6 +1478,7 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
 #pragma unroll
             for (int k = 0; k < E; ++k) gstore<NTS>(op + out_off(k) + (long long)h * omap.stride, VT::to_g(cscale(v[k], sc)));
         }
+    }
     }
 #endif
 }
@@ -1978,6 +1992,9 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
 #ifndef DFFT_X_DIF2_1024
 #define DFFT_X_DIF2_1024 1
 #endif
+#ifndef DFFT_DIF2_HALF
+#define DFFT_DIF2_HALF 0
+#endif
         if constexpr (!std::is_void<PH>::value && ((VecTraits<V>::LANES == 2 && P::N >= 2048) || (DFFT_X_DIF2_1024 && P::N == 1024 && VecTraits<V>::LANES == 1))) {  // (fp64 2048: 108-116 bytes of scratch next to the rotated-row image -- stays on the paired tiles)
             // forward X pass of lengths whose full-line tile does not fit the LDS (2048 points): DIF-split full-line tiles with the
             // staged transposed store (round 6; fft_dif2_tiles_kernel, TOUT).  DFFT_X_DIF2=0: the paired half-line tiles of rounds 2-5.
@@ -2040,6 +2057,17 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
                 L.omap.blk % (2 * PH::T) == 0 && (!rot || rot_tile)) {
                 if (rot) {
                     if (L.dir > 0) {
+#if DFFT_DIF2_HALF
+                        // experiment (round 6): the packing Y pass of 2048-point column pairs on HALF-line tiles (4 pairs: 64 KiB half tile +
+                        // 16 KiB table, two workgroups per CU) -- DFFT_Y_DIF2_HALF=1 selects it
+                        if constexpr (VecTraits<V>::LANES == 2 && P::N == 2048) {
+                            static const bool half = [] {
+                                const char* e = getenv("DFFT_Y_DIF2_HALF");
+                                return e && *e == '1';
+                            }();
+                            if (half && sout && L.ncols % (CBF / 2) == 0) return launch_dif2<V, PH, CBF / 2, +1, false, true, true, true, 1>(L, stream);
+                        }
+#endif
                         if (sout) return launch_dif2<V, PH, CBF, +1, false, true, true, true, 1>(L, stream);
                         return launch_dif2<V, PH, CBF, +1, false, false, true, true, 1>(L, stream);
                     }
