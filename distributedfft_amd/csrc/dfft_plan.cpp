@@ -463,7 +463,15 @@ struct StageClock {
 // Planes per phase of the one-launch YZ stage for a slab (or part) of nx planes: one that fits the 256 MiB Infinity Cache is ONE
 // phase; larger ones are cut into equal phases of at most 230 MiB -- head-room instead of the largest possible size, see
 // dfft_plan_create; a short last phase costs more than it saves.  DFFT_CHUNK_PLANES overrides.
-static long long zy_phase_planes(const dfft_plan_s* p, long long nx) {
+// Forward PACKED launches (P > 1: the column units stream their results into the send buffer, so a phase is only READ from the cache) fill
+// the cache instead -- 256 MiB: every phase boundary costs about 30 us of a rank's stage whatever the phase size (per rank at 512^3 fp64,
+// P = 4, 128 planes: 2 phases of 64 planes 0.304 ms, 3 x 43 0.319, 4 x 32 0.394, 8 x 16 0.50, one phase of 512 MiB 0.377;
+// profiles/r06/experiments/packed_phase_curve_512_P4.log), so fewer phases win as long as one still fits: 512^3 per rank at P = 2
+// 5 x 52 -> 4 x 64 planes 0.597 -> 0.579 ms, at P = 4 3 x 43 -> 2 x 64 0.312 -> 0.300; config 4 at P = 2 14 -> 13 phases 2.03 -> 1.98.
+// (What a boundary costs is the window in which row and column units run side by side: an interleaved ticket order -- rows of phase s
+// alternating plane by plane with the columns of phase s - 1, no boundaries at all -- was built and measured at 0.335-0.46 ms against 0.309
+// there, 1.42-1.82 against 1.155 on one GPU; profiles/r06/experiments/zy_interleaved_order.log.  Homogeneous phases, as few as fit.)
+static long long zy_phase_planes(const dfft_plan_s* p, long long nx, bool packed_fwd = false) {
     static const long long forced = [] {
         const char* e = getenv("DFFT_CHUNK_PLANES");
         return e ? atoll(e) : 0ll;
@@ -471,7 +479,7 @@ static long long zy_phase_planes(const dfft_plan_s* p, long long nx) {
     const long long plane_b = p->N[1] * p->N[2] * (long long)elem_bytes(p->dtype);
     if (forced > 0) return std::min(forced, nx);
     if (nx * plane_b <= (256ll << 20)) return nx;
-    const long long fit = std::max(1ll, (230ll << 20) / plane_b), nch = (nx + fit - 1) / fit;
+    const long long fit = std::max(1ll, ((packed_fwd ? 256ll : 230ll) << 20) / plane_b), nch = (nx + fit - 1) / fit;
     return (nx + nch - 1) / nch;
 }
 
@@ -500,7 +508,7 @@ static int launch_zy_stage(dfft_plan_s* p, const void* src, void* w, long long w
     L.w_plane = w_plane; DFFT_ZY_SET_PITCH(L, (p->wbuf && w == p->wbuf) ? p->wl.pitch : p->N[2]);
     L.plane0 = x0;
     L.nplanes = nx;
-    L.chunk = zy_phase_planes(p, nx);
+    L.chunk = zy_phase_planes(p, nx, packed && p->direction == DFFT_FORWARD);
     L.ctl = p->zy_ctl;
     L.twz = twz;
     L.twy = twy;
@@ -1821,7 +1829,7 @@ int dfft_plan_describe(dfft_plan_t plan, char* buf, int len) {
     if (!plan || !buf || len < 64) return fail(DFFT_EINVAL, "dfft_plan_describe: bad arguments");
     const dfft_plan_s* p = plan;
     const bool         one = p->zy_on && !(p->flags & DFFT_PLAN_UNFUSED);
-    const long long    cp = one ? zy_phase_planes(p, p->xs) : (p->chunk_planes > 0 ? p->chunk_planes : p->xs);
+    const long long    cp = one ? zy_phase_planes(p, p->xs, p->exch && p->direction == DFFT_FORWARD) : (p->chunk_planes > 0 ? p->chunk_planes : p->xs);
     const long long    nch = cp > 0 ? (p->xs + cp - 1) / cp : 1;
     const bool         fused = !(p->flags & DFFT_PLAN_UNFUSED);
     snprintf(buf, (size_t)len,
