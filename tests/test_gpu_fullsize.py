@@ -23,6 +23,10 @@ CONFIGS = [
     pytest.param((512, 512, 512), 4, "f64", True, id="C3-512^3-fp64-P4-overlap"),
     pytest.param((512, 512, 512), 8, "f64", True, id="512^3-fp64-P8-overlap"),
     pytest.param((2048, 2048, 1024), 8, "f32", True, id="C5-2048x2048x1024-fp32-P8-overlap"),
+    # config 4 overlapped: at P = 8 the X-plane parts are sized like cache chunks (3 x 40 + 8 planes, two launches per part), at P = 4 ONE
+    # launch of the YZ stage serves all parts on 96-row Y sub-blocks
+    pytest.param((1024, 768, 512), 8, "f64", True, id="C4-1024x768x512-fp64-P8-overlap"),
+    pytest.param((1024, 768, 512), 4, "f64", True, id="C4-1024x768x512-fp64-P4-overlap"),
 ]
 TOL = {"f64": 1e-11, "f32": 5e-4}
 
@@ -92,6 +96,10 @@ def test_fullsize_properties(gpu, N, P, prec, overlap):
         outs.append(b)
         plans.append(api.Plan(n0, n1, n2, a, b, comm, g, P, api.FORWARD,
                               api.PLAN_INPUT_FROM_IN | (api.PLAN_OVERLAP if overlap else 0)))
+    if overlap and N == (1024, 768, 512):   # the plan really is what the case is listed for (dfft_plan_describe)
+        desc = plans[0].describe()
+        want = "overlap_parts=40 " if P == 8 else "parts_in_one_launch=1 "
+        assert want in desc and ("yz_stage=one-launch-lazy" in desc) == (P == 4), desc
     _run(plans)
 
     # expected: 1 everywhere (impulse) + a_m * N at (kx, ky, kz); layout out_d[yy][z][kx]
