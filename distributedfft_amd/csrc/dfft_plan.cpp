@@ -1387,7 +1387,19 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                               fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2);
         const long long ysub = p->ys / std::max(1, p->ycuts);
         const bool      pays = (ysub * n2 * S) % (256ll << 10) == 0;
-        if (possible && !(re && *re == '0') && (pays || (re && *re == '1'))) p->rot_elems = (int)(3 * 128 / S);
+        // How far: 3 cache lines per X plane (the pad of the single-GPU hand-over buffer, round 2) -- but 2 lines where the X axis is long
+        // and the received planes lie at least 1 MiB apart.  Round 6 (profiles/r06/experiments/rot_lines_*.log, DFFT_ROT_LINES swept, four
+        // plans per point): a tile of the X pass walks N0 segments (plane stride + rotation) apart; with 2048 planes 2 MiB apart (config 5's
+        // rank at P = 8) 1 line 1.85 ms, 2 lines 1.67, 3 lines 1.89, 4 lines 1.98, 6 lines 1.67 -- odd multiples of 256 bytes spread the
+        // walk over all channels, 384 bytes over two thirds of them, 512 over half.  2 against 3 lines: 1024^3 fp64 at P = 8 0.842 -> 0.737 ms,
+        // 1024^3 fp32 at P = 4 0.801 -> 0.750, config 4 at P = 4 0.593 -> 0.569; no difference with 512 planes, and with planes
+        // 512-768 KiB apart (512^3 overlapped at P = 4 / 8, config 4 at P = 8) 3 lines stay 2-10 % ahead.  DFFT_ROT_LINES=n overrides.
+        if (possible && !(re && *re == '0') && (pays || (re && *re == '1'))) {
+            int         lines = (n0 >= 1024 && ysub * n2 * S >= (1ll << 20)) ? 2 : 3;
+            const char* rl = getenv("DFFT_ROT_LINES");
+            if (rl && atoi(rl) > 0) lines = atoi(rl);
+            p->rot_elems = (int)(lines * 128 / S);
+        }
     }
     {
         // kernel-variant switches (A/B measurements; results are bit-identical either way), read when the plan is created:
