@@ -1378,7 +1378,7 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
         // Rotated rows in the exchange buffers (dfft_plan_s::rot_elems): the same remedy for the P > 1 pipeline that the padded
         // hand-over buffer is for the single-GPU one.  Every rank derives it from (N, P, precision, flags) alone -- both ends of
         // every message must agree.  Where: fused, even splits, tuned kernels on all three axes, rows of whole lines and a
-        // power-of-two length, received planes a multiple of 256 KiB apart (other strides spread over the channels by
+        // power-of-two length, received planes a multiple of 128 KiB apart (other strides spread over the channels by
         // themselves).  DFFT_ROT=0 / 1 forces it off / on (wherever it is possible).
         const char*     re = getenv("DFFT_ROT");
         const long long S = (long long)elem_bytes(dtype);
@@ -1386,7 +1386,10 @@ int dfft_plan_create(dfft_plan_t* plan, long long n0, long long n1, long long n2
                               n1 % total_devices == 0 && (n2 & (n2 - 1)) == 0 && (n2 * S) % 128 == 0 && n2 * S >= 256 && n2 < (1ll << 30) &&
                               fft_length_tuned((int)n0) && fft_length_tuned((int)n1) && fft_length_tuned((int)n2);
         const long long ysub = p->ys / std::max(1, p->ycuts);
-        const bool      pays = (ysub * n2 * S) % (256ll << 10) == 0;
+        // (round 6: 128 KiB, not 256 -- with received planes an odd multiple of 128 KiB apart the rotation is worth 7-10 % of the X pass in
+        // five shapes of seven, nothing in one, -4 % in one: config 4's overlapped rank at P = 8, 384 KiB, 0.326 -> 0.299 ms;
+        // profiles/r06/experiments/rot_pays_128k.log)
+        const bool      pays = (ysub * n2 * S) % (128ll << 10) == 0;
         // How far: 3 cache lines per X plane (the pad of the single-GPU hand-over buffer, round 2) -- but 2 lines where the X axis is long
         // and the received planes lie at least 1 MiB apart.  Round 6 (profiles/r06/experiments/rot_lines_*.log, DFFT_ROT_LINES swept, four
         // plans per point): a tile of the X pass walks N0 segments (plane stride + rotation) apart; with 2048 planes 2 MiB apart (config 5's
