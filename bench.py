@@ -462,13 +462,18 @@ def main():
             forms_differ = (not stub_mode and hasattr(plan, "describe")
                             and plan.describe().split("yz_stage=")[1].split()[0] != plan_s.describe().split("yz_stage=")[1].split()[0])
             close = same_bits
-            if not same_bits and forms_differ:
+            if not same_bits and not stub_mode:
+                # (also where a pass of the overlapped plan runs another kernel of the same length -- e.g. a 1024-point fp32 Y axis whose
+                # 64-row destination sub-blocks are below the DIF-split kernel's 128-row grain, tools/fuzz_parity.py: last bits differ)
                 scale_r = b2[:count].abs().max().item()
                 referee_rel = ((b2[:count] - b[:count]).abs().max().item() / scale_r) if scale_r > 0 else float("inf")
-                close = referee_rel <= 1e-13
-                referee_forms_note = (f"the serial and the overlapped plan run different forms of the YZ stage ({plan_s.describe().split('yz_stage=')[1].split()[0]} / "
-                                      f"{plan.describe().split('yz_stage=')[1].split()[0]}), which agree to the last bit or two by construction: compared to "
-                                      f"1e-13 of max|X| instead of bit for bit (max relative difference on this rank {referee_rel:.2e})")
+                referee_tol = 1e-13 if args.precision == "fp64" else 2e-6
+                close = referee_rel <= referee_tol
+                why = (f"run different forms of the YZ stage ({plan_s.describe().split('yz_stage=')[1].split()[0]} / "
+                       f"{plan.describe().split('yz_stage=')[1].split()[0]}), which agree to the last bit or two by construction" if forms_differ
+                       else "select different kernels for a pass (same transform, different last bits)")
+                referee_forms_note = (f"the serial and the overlapped plan {why}: compared to {referee_tol:g} of max|X| instead of bit for bit "
+                                      f"(max relative difference on this rank {referee_rel:.2e})")
             same_t = torch.tensor([1.0 if close else 0.0, 1.0 if same_bits else 0.0], dtype=torch.float64)
             dist.all_reduce(same_t, op=dist.ReduceOp.MIN)
             referee_same = same_t[0].item() == 1.0
@@ -744,11 +749,11 @@ def main():
                     "t2": round(float(serial_stage[2]) * 1e3, 4), "t3": round(float(serial_stage[3]) * 1e3, 4)}
                 result["overlap_result_bit_identical"] = same
                 if referee_forms_note is not None:
-                    result["overlap_result_within_1e-13"] = referee_same
+                    result["overlap_result_within_referee_tolerance"] = referee_same
             elif referee_same is not None:
                 result["overlap_result_bit_identical"] = referee_bits  # the referee's findings before the fallback
                 if referee_forms_note is not None:
-                    result["overlap_result_within_1e-13"] = referee_same
+                    result["overlap_result_within_referee_tolerance"] = referee_same
             result["pipeline"] = "overlapped" if overlap else "serial"
             if comm_fallback is not None:
                 result["exchange_fallback"] = comm_fallback
