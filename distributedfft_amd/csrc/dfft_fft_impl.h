@@ -1484,6 +1484,108 @@ fft_dif2_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>:
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Radix-3 split at load time (round 6, last session; -DDFFT_DIF3=1, DFFT_DIF3=1): full-line column tiles for N = 3 * NT whose own tile
+// leaves room for ONE workgroup per CU only (768 points: 96 KiB + table).  Thread j of a column holds the points n = j + T k, n + NT and
+// n + 2 NT (k < E; PT = the NT-point plan, E T = NT) -- the three inputs of every first-stage butterfly of a decimation-in-frequency
+// radix-3 step --
+//     u_r[n] = (sum_q x[n + q NT] w3^(q r)) * W_N^(n r)   ->   X[3 m + r] = DFT_NT(u_r)[m],   r = 0, 1, 2
+// and the three NT-point transforms go through one (NT x CB) LDS tile one after the other: 768 fp64 points need 32 KiB + 12 KiB of
+// tables, so THREE workgroups share a CU (fft_dif2_tiles_kernel's argument for 1024 points, profiles/r06/README.md section 1g), with two
+// exchanges per sub-transform instead of three over the whole 96 KiB tile.  W_N^n and W_N^(2 n) (n < NT) come from the N-point table;
+// the NT-point stages read every third entry of it, stage-major, from the LDS copy.  Fast path only: whole tiles, both sides keep the
+// columns of a line together, input blocks multiples of T points, output blocks multiples of 3 T.
+template <class V, class PT, int CB> struct Dif3Geom {
+    using W = typename VecTraits<V>::W;
+    static constexpr size_t TW_BYTES = ((size_t)3 * PT::N * sizeof(W) + 15) / 16 * 16;  // stage-major table + W^n + W^(2n)
+    static constexpr size_t TILE_BYTES = (size_t)PT::N * CB * sizeof(V);
+    static constexpr size_t LDS_BYTES = TW_BYTES + TILE_BYTES;
+    static constexpr int    PER_CU = (int)(160 * 1024 / LDS_BYTES) < 1 ? 1 : (int)(160 * 1024 / LDS_BYTES);
+    static constexpr int    WAVES_PER_EU = (PER_CU * CB * PT::T + 255) / 256;  // waves per SIMD when PER_CU workgroups are resident
+};
+template <class V, class PT, int CB, int DIR, bool NTL, bool NTS, int ROT = 0>
+__global__ void __attribute__((amdgpu_flat_work_group_size(1, CB * PT::T), amdgpu_waves_per_eu(Dif3Geom<V, PT, CB>::WAVES_PER_EU)))
+fft_dif3_tiles_kernel(const typename VecTraits<V>::G* in, typename VecTraits<V>::G* out, const typename VecTraits<V>::W* __restrict__ tw,
+                      AxisMap imap, AxisMap omap, TileMap itile, TileMap otile, unsigned ntiles, unsigned tiles_per_a, unsigned a_first,
+                      double scale, RotMap rm) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr int E = PT::E, T = PT::T, GT = CB * T, NT = PT::N;
+    static_assert(PT::S > 1 && E * T == NT && GT <= 1024, "radix-3 split tiles: multi-stage third plan, one workgroup per tile");
+    using DG = Dif3Geom<V, PT, CB>;
+    extern __shared__ __attribute__((aligned(16))) char dfft_smem[];
+    W* ldstw = reinterpret_cast<W*>(dfft_smem);  // [0, NT) stage-major table of the NT-point stages, [NT, 2 NT) W_N^n, [2 NT, 3 NT) W_N^(2 n)
+    V* lds = reinterpret_cast<V*>(dfft_smem + DG::TW_BYTES);
+    constexpr int NWV = owned_waves<V, CB, T>();
+    const int     tid = threadIdx.x, c = tid % CB, j = tile_j<CB, NWV>(tid);
+    fill_stage_major<W, PT, 0, DIR, NWV, 3>(ldstw, tw, tid, GT);
+    auto fperm = [](int jj) -> int {  // (as in fft_dif2_tiles_kernel: the factors in the order the lanes of a wavefront read them)
+        if constexpr (NWV > 1) return (jj % NWV) * (T / NWV) + jj / NWV;
+        else return jj;
+    };
+    for (int i = tid; i < NT; i += GT) {
+        W w1 = tw[i], w2 = tw[2 * i];
+        if (DIR < 0) {
+            w1.y = -w1.y;
+            w2.y = -w2.y;
+        }
+        const int at = (i / T) * T + fperm(i % T);
+        ldstw[NT + at] = w1;
+        ldstw[2 * NT + at] = w2;
+    }
+    const W* f1 = ldstw + NT + fperm(j);  // factors of point k: f1[T k], f2[T k]
+    const W* f2 = ldstw + 2 * NT + fperm(j);
+    __syncthreads();
+    unsigned iuni[3 * E], ouni[E];
+#pragma unroll
+    for (int kk = 0; kk < 3 * E; ++kk) {
+        const int ib = (T * kk) / imap.blk;
+        iuni[kk] = (unsigned)(block_term(imap, ib) + (long long)(T * kk - ib * imap.blk) * imap.stride);
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int ob = (3 * T * k) / omap.blk;
+        ouni[k] = (unsigned)(block_term(omap, ob) + (long long)(3 * T * k - ob * omap.blk) * omap.stride);
+    }
+    const long long ithr = (long long)j * imap.stride + (long long)c * imap.cstride;
+    const long long othr = (long long)(3 * j) * omap.stride + (long long)c * omap.cstride;
+    const typename real_of<W>::type sc = (typename real_of<W>::type)scale;
+    for (unsigned t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const unsigned al = t / tiles_per_a, b = t - al * tiles_per_a, a = al + a_first;
+        int cbi = (int)(b * CB), cbo = (int)(b * CB);
+        if constexpr (ROT == 1) {  // rotated rows of an exchange buffer (RotMap mode 1): the whole tile moves inside its row
+            const int r = rm.rot * (int)(a + (unsigned)rm.a0);
+            if (rm.in_mode == 1) cbi = (cbi + r) & rm.mask;
+            if (rm.out_mode == 1) cbo = (cbo + r) & rm.mask;
+        }
+        const GV* ip = in + (long long)a * itile.a_stride + (long long)cbi * itile.b_stride + ithr;
+        GV*       op = out + (long long)a * otile.a_stride + (long long)cbo * otile.b_stride + othr;
+        V         v0[E], v1[E], v2[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            v0[k] = VT::from_g(gload<NTL>(ip + (long long)iuni[k]));
+            v1[k] = VT::from_g(gload<NTL>(ip + (long long)iuni[k + E]));
+            v2[k] = VT::from_g(gload<NTL>(ip + (long long)iuni[k + 2 * E]));
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            V u[3] = {v0[k], v1[k], v2[k]};
+            Butterfly<3, DIR, V>::run(u);
+            v0[k] = u[0];
+            v1[k] = cmul(u[1], f1[T * k]);  // W_N^(j + T k)
+            v2[k] = cmul(u[2], f2[T * k]);  // W_N^(2 (j + T k))
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            V* v = r == 0 ? v0 : (r == 1 ? v1 : v2);
+            run_stages<V, PT, 0, DIR, CB, false, false, TW_LDS, false, 1, 1, NWV>(v, ldstw, lds, j, c);
+#pragma unroll
+            for (int k = 0; k < E; ++k) gstore<NTS>(op + (long long)ouni[k] + (long long)r * omap.stride, VT::to_g(cscale(v[k], sc)));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Column tiles whose INPUT side is the transposed one ([..][z][kx], kx fastest: the inverse X pass; reference fftX backward,
 // fft_mpi_3d_api.cpp:553-570) -- the mirror image of the staged transposing store of fft_tiles_kernel (round 4).  On that side
 // the columns of a tile are far apart and the FFT index is the contiguous one, so fft_tiles_kernel reads 128-byte pieces in fp64
@@ -1741,6 +1843,43 @@ template <class V, class PH, int CB, int DIR, bool NTL, bool NTS, bool BIN, bool
                        L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
     e = hipGetLastError();
     if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * PH::T);
+    return hipSuccess;
+}
+
+template <class V, class PT, int CB, int DIR, bool NTL, bool NTS, int ROT = 0> hipError_t launch_dif3(const FftLaunch& L, hipStream_t stream) {
+    using VT = VecTraits<V>;
+    using W = typename VT::W;
+    using GV = typename VT::G;
+    constexpr size_t LDS_BYTES = Dif3Geom<V, PT, CB>::LDS_BYTES;
+    auto kern = fft_dif3_tiles_kernel<V, PT, CB, DIR, NTL, NTS, ROT>;
+    static std::atomic<int> blocks_per_cu[64];  // 0 = not set up on that device yet
+    static std::mutex       setup_mutex;
+    int         dev = 0;
+    hipError_t  e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (blocks_per_cu[dev].load(std::memory_order_acquire) == 0) {
+        std::lock_guard<std::mutex> lk(setup_mutex);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+        if (e != hipSuccess) return launch_debug(e, "hipFuncSetAttribute", (int)LDS_BYTES, CB * PT::T);
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, CB * PT::T, LDS_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            occ = 1;
+        }
+        blocks_per_cu[dev].store(occ > 0 ? occ : 1, std::memory_order_release);
+    }
+    const long long tiles_per_a = L.ncols / CB, ntiles = L.na * tiles_per_a;
+    if (ntiles <= 0) return hipSuccess;
+    if (ntiles >= (1ll << 31)) return hipErrorInvalidValue;
+    long long grid = (long long)device_info().cus * blocks_per_cu[dev].load(std::memory_order_relaxed);
+    if (L.grid_limit > 0 && grid > L.grid_limit) grid = L.grid_limit;
+    if (grid > ntiles) grid = ntiles;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(CB * PT::T), LDS_BYTES, stream, (const GV*)L.in, (GV*)L.out, (const W*)L.tw, L.imap,
+                       L.omap, L.itile, L.otile, (unsigned)ntiles, (unsigned)tiles_per_a, (unsigned)L.a_first, L.scale == 0.0 ? 1.0 : L.scale, L.rot);
+    e = hipGetLastError();
+    if (e != hipSuccess) return launch_debug(e, "kernel launch", (int)LDS_BYTES, CB * PT::T);
     return hipSuccess;
 }
 
@@ -2025,6 +2164,33 @@ template <class V, class P, class PH = void, int CBO = 0> hipError_t launch_plan
                 return L.dir > 0 ? launch_dual<V, P, CBC, +1, true>(L, stream) : launch_dual<V, P, CBC, -1, true>(L, stream);
             }
         }
+#ifndef DFFT_DIF3
+#define DFFT_DIF3 0
+#endif
+#if DFFT_DIF3
+        if constexpr (P::N == 768 && VecTraits<V>::LANES == 1) {
+            // radix-3 split tiles (fft_dif3_tiles_kernel): three 256-point sub-transforms through a 32 KiB tile, three workgroups per CU
+            using PT3 = Plan<256, 8, 8, 8, 4>;
+            constexpr int CB3 = 128 / (int)sizeof(V);
+            static const bool dif3 = [] {
+                const char* e = getenv("DFFT_DIF3");
+                return e && *e == '1';
+            }();
+            const bool lines = L.imap.cstride == 1 && L.itile.b_stride == 1 && L.omap.cstride == 1 && L.otile.b_stride == 1;
+            const bool even3 = L.ncols % CB3 == 0 && L.imap.last_delta == 0 && L.omap.last_delta == 0;
+            const bool fit3 = axis_max_offset(L.imap, P::N) < (1ll << 32) && axis_max_offset(L.omap, P::N) < (1ll << 32);
+            const bool rot3 = !rot || (L.rot.in_mode != 2 && L.rot.out_mode != 2);
+            if (dif3 && !general && lines && even3 && fit3 && rot3 && L.imap.blk % PT3::T == 0 && L.omap.blk % (3 * PT3::T) == 0) {
+                const bool s_in = (L.hints & FFT_HINT_STREAM_IN) != 0, s_out = (L.hints & FFT_HINT_STREAM_OUT) != 0;
+                if (rot) {
+                    if (L.dir > 0) return s_out ? launch_dif3<V, PT3, CB3, +1, false, true, 1>(L, stream) : launch_dif3<V, PT3, CB3, +1, false, false, 1>(L, stream);
+                    return s_in ? launch_dif3<V, PT3, CB3, -1, true, false, 1>(L, stream) : launch_dif3<V, PT3, CB3, -1, false, false, 1>(L, stream);
+                }
+                if (L.dir > 0) return s_out ? launch_dif3<V, PT3, CB3, +1, false, true>(L, stream) : launch_dif3<V, PT3, CB3, +1, false, false>(L, stream);
+                return s_in ? launch_dif3<V, PT3, CB3, -1, true, false>(L, stream) : launch_dif3<V, PT3, CB3, -1, false, false>(L, stream);
+            }
+        }
+#endif
         if constexpr (!std::is_void<PH>::value) {
             // full-line tiles through the DIF split whenever both sides keep the 8 (16 fp32) columns of a line together
             constexpr int CBF = 128 / (int)sizeof(V);
