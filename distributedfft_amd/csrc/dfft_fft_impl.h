@@ -330,6 +330,60 @@ __device__ __forceinline__ void fill_stage_major(W* dst, const W* __restrict__ t
 //   TW_GLOBAL N-entry table read through L1/L2 (only when the LDS is needed for the exchange tile, e.g. N = 2048)
 enum { TW_REG = 0, TW_LDS = 1, TW_GLOBAL = 2 };
 
+// Cross-lane form of a wave-owned exchange (round 6, experiment: -DDFFT_XLANE=1; VERDICT r05 Next-1c).  Under the wave-interleaved labelling
+// with NW = 8 waves, 8-column tiles and T = 64 butterfly threads a wavefront holds the ids w + 8 g (g = lane / 8, column = lane % 8).
+// For a stage with NS R = 64 = T (NS = 8 n) the scatter / gather sends the result (g, q, r) to lane group (r, g mod n) as point
+// g / n + R q: for each of the thread's B butterflies a TRANSPOSE between the upper lane-group bits and the register index r of 16-byte
+// elements, followed by a renaming of registers.  gfx950 does a round of such a transpose on a register pair without selects:
+// v_permlane32_swap (upper half of a <-> lower half of b), v_permlane16_swap (odd rows of a <-> even rows of b); lane bit 3 takes two
+// v_mov_b32_dpp row_ror:8 with bank masks.  Cases: the exchange between the radix-8 stages of 512 / 1024 / 2048 = 8 8 ... (three rounds),
+// the one behind the third radix-4 stage of 768 = 4 4 4 4 3 (NS = 16: two rounds, no DPP).  Pure data movement: bit-identical results.
+// tools/xlane_probe.hip measures the exchange alone (profiles/r06/README.md section 1i).
+#ifndef DFFT_XLANE
+#define DFFT_XLANE 0
+#endif
+typedef unsigned xl_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned xl_u32x4 __attribute__((ext_vector_type(4)));
+template <int NW, int CB, int T, int NS, int R, int S, class V> constexpr bool xlane_exchange() {
+    return DFFT_XLANE && NW == 8 && CB == 8 && T == 64 && S > 0 && sizeof(V) == 16 && NS % 8 == 0 && NS * R == 64 && (R == 8 || R == 4 || R == 2);
+}
+// one round on a register pair: lanes whose bit BIT is clear keep a and receive the partner's a into b, the others keep b and receive the
+// partner's b into a
+template <int BIT, class V> __device__ __forceinline__ void xlane_round(V& a, V& b) {
+    xl_u32x4 x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if constexpr (BIT == 5) {
+            const xl_u32x2 r = __builtin_amdgcn_permlane32_swap(x[d], y[d], false, false);
+            x[d] = r.x;
+            y[d] = r.y;
+        } else if constexpr (BIT == 4) {
+            const xl_u32x2 r = __builtin_amdgcn_permlane16_swap(x[d], y[d], false, false);
+            x[d] = r.x;
+            y[d] = r.y;
+        } else {
+            static_assert(BIT == 3, "lane bits 3..5");
+            const unsigned nx = __builtin_amdgcn_update_dpp(x[d], y[d], 0x128 /* row_ror:8 */, 0xf, 0xc, false);
+            const unsigned ny = __builtin_amdgcn_update_dpp(y[d], x[d], 0x128, 0xf, 0x3, false);
+            x[d] = nx;
+            y[d] = ny;
+        }
+    }
+    __builtin_memcpy(&a, &x, 16);
+    __builtin_memcpy(&b, &y, 16);
+}
+template <int BIT0, int RB, int R, int B, class V> __device__ __forceinline__ void xlane_transpose(V* v, int q) {
+    // register bit RB of r <-> lane bit BIT0 + RB
+    if constexpr (RB >= 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (!(r & (1 << RB))) xlane_round<BIT0 + RB>(v[q + r * B], v[q + (r | (1 << RB)) * B]);
+        xlane_transpose<BIT0, RB - 1, R, B>(v, q);
+    }
+}
+
 // PH = 2: the tile (N x CB elements) is twice what the LDS holds, so every exchange runs in two phases -- first the threads
 // of columns [0, CB/2), then those of [CB/2, CB) -- through one half-size buffer.  HBM accesses keep full 128-byte lines
 // (all CB columns of a row segment are loaded/stored together); only the LDS issue slots double.
@@ -412,6 +466,17 @@ __device__ __forceinline__ void run_stages(V* v, const typename VecTraits<V>::W*
             for (int q = 0; q < B; ++q)
 #pragma unroll
                 for (int r = 0; r < R; ++r) t[((q * T) / NS) * (NS / T) * R + ((q * T) % NS) / T + r * (NS / T)] = v[q + r * B];
+#pragma unroll
+            for (int k = 0; k < E; ++k) v[k] = t[k];
+        } else if constexpr (PH == 1 && xlane_exchange<NW, CB, T, NS, R, S, V>()) {
+            constexpr int LR = R == 8 ? 3 : (R == 4 ? 2 : 1);  // bits of r; the lane bits are the top LR bits of the lane group: 6 - LR .. 5
+            V t[E];
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                xlane_transpose<6 - LR, LR - 1, R, B>(v, q);
+#pragma unroll
+                for (int i = 0; i < R; ++i) t[i + R * q] = v[q + i * B];
+            }
 #pragma unroll
             for (int k = 0; k < E; ++k) v[k] = t[k];
         } else if constexpr (PH == 1) {
