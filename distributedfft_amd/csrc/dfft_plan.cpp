@@ -834,6 +834,17 @@ static int execute_backward(dfft_plan_s* p, bool sync) {
     else if (one_launch) DFFT_TRY(launch_zy_stage(p, nullptr, fused ? ydst : ybuf, yl.plane, ybuf, y_unpacks ? p->buf1 : nullptr, y_unpacks, 0, p->xs));
     for (long long x0 = 0; !one_launch && x0 < p->xs; x0 += cp) {  // Y then Z per cache-sized chunk of planes (see execute_forward)
         const long long nx = std::min(cp, p->xs - x0);
+        // single-GPU plans with a hand-over buffer, slab cut into cache chunks: Z rows first, like the one-launch stage above (round 6, last
+        // session) -- rows hand-over buffer (HBM, contiguous) -> result buffer (natural layout, left in the Infinity Cache), then Y columns in
+        // place on the result buffer: the strided side moves from HBM reads to the cache-resident chunk.  Inverse YZ stage 1024^3 fp32
+        // 7.10 -> 5.93 ms, 2048 x 1024 x 512 fp64 13.08 -> 11.16, 512^3 fp32 0.89 -> 0.71; whole backward transform -7 ... -14 %
+        // (profiles/r06/experiments/lib_ab_inverse_rows_first_chunks.log).  Same switches as the one-launch stage: DFFT_ZY_INV_ROWS_FIRST=0
+        // or DFFT_ZY_LAZY=0 (the forms the bit-identity tests compare with each other) keep columns first.
+        if (xw && cp < p->xs && p->zy_inv_rows_first && p->zy_lazy) {
+            DFFT_TRY(fft_rows(p->wbuf, ybuf, (int)n2, nx * n1, p->dtype, p->direction, p->stream, x0 * n1, FFT_HINT_STREAM_IN, 1.0, ly, lnat, n1));
+            DFFT_TRY(launch_y(p, ybuf, ybuf, false, false, x0, nx));
+            continue;
+        }
         if (y_unpacks) DFFT_TRY(launch_y(p, p->buf1, fused ? ydst : ybuf, false, true, x0, nx, chunked ? FFT_HINT_STREAM_IN : 0, nullptr, &yl));
         else if (xw) DFFT_TRY(launch_y(p, p->wbuf, p->wbuf, false, false, x0, nx, 0, &yl, &yl));
         else DFFT_TRY(launch_y(p, p->buf2, ybuf, false, false, x0, nx));
