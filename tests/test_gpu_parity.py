@@ -395,6 +395,47 @@ def test_one_launch_t0_is_bit_identical(gpu, N, chunk, monkeypatch):
         assert (outs[mode][1] / n - a).abs().max().item() < 1e-11
 
 
+@pytest.mark.parametrize("N,prec,chunk", [((16, 256, 256), "f32", 5), ((12, 512, 128), "f32", 4), ((9, 1024, 64), "f64", 2), ((10, 96, 2048), "f64", 3),
+                                          ((7, 768, 256), "f32", 3)])
+def test_inverse_chunk_loop_rows_first_vs_oracle(gpu, N, prec, chunk, monkeypatch):
+    """Single-GPU backward plans that cut their slab into cache chunks on a hand-over buffer run the inverse YZ stage Z rows first
+    (hand-over buffer -> result buffer, then Y columns in place on the cache-resident chunk; round 6, dfft_plan.cpp execute_backward).
+    Shapes the one-launch stage does not take (fp32, or a 1024- / 2048-point fp64 axis), several chunks with a ragged last one: the
+    backward transform of the forward result against numpy's inverse and against the input (round trip), and against the
+    columns-first order (DFFT_ZY_INV_ROWS_FIRST=0) to the last bits."""
+    import torch
+    from distributedfft_amd import api
+    monkeypatch.setenv("DFFT_PAD", "1")            # small slabs get the hand-over buffer too
+    monkeypatch.setenv("DFFT_CHUNK_PLANES", str(chunk))
+    n = N[0] * N[1] * N[2]
+    cdt, tol = (np.complex128, 1e-11) if prec == "f64" else (np.complex64, 5e-4)
+    x = so.random_input(N, seed=N[1] + 7).astype(cdt)
+    a = torch.from_numpy(x.reshape(-1)).to(gpu)
+    outs = {}
+    for order in ("rows", "cols"):
+        if order == "cols":
+            monkeypatch.setenv("DFFT_ZY_INV_ROWS_FIRST", "0")
+        b, c = torch.zeros_like(a), torch.zeros_like(a)
+        p = api.Plan(*N, a, b, None, 0, 1, api.FORWARD, api.PLAN_INPUT_FROM_IN)
+        q = api.Plan(*N, b, c, None, 0, 1, api.BACKWARD, api.PLAN_INPUT_FROM_IN)
+        assert "yz_stage=two-launches-per-chunk" in q.describe() and "handover=padded-buffer" in q.describe(), q.describe()
+        p.execute()
+        p.sync()
+        for _ in range(2):
+            q.execute(api.EXEC_NO_TIMING)
+        q.sync()
+        outs[order] = c.clone()
+        fw = b.cpu().numpy().reshape(N[1], N[2], N[0])
+        p.destroy()
+        q.destroy()
+    exp = np.fft.ifftn(np.transpose(fw, (2, 0, 1)).astype(np.complex128)) * n      # the unnormalised inverse, [x][y][z]
+    for order in ("rows", "cols"):
+        got = outs[order].cpu().numpy().reshape(N)
+        assert np.abs(got - exp).max() / np.abs(exp).max() < tol, order
+        assert np.abs(got / n - x).max() / np.abs(x).max() < tol, order
+    assert ((outs["rows"] - outs["cols"]).abs().max() / outs["cols"].abs().max()).item() < (1e-14 if prec == "f64" else 1e-6)
+
+
 @pytest.mark.parametrize("direction", [+1, -1])
 def test_one_launch_t0_failure_is_loud_and_recovered(gpu, direction, monkeypatch):
     """A one-launch YZ stage that gives up must never hand back garbage with DFFT_OK.  DFFT_ZY_FAULT=n makes launch n
